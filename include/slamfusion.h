@@ -1,0 +1,243 @@
+/*
+ * slamfusion.h — C ABI of libslamfusion.so: MI355X-native (gfx950, hand-written HIP)
+ * scan-to-map registration hot path, drop-in for that path of
+ * viniciusvidal2/slam-sensor-fusion.  Plain C types only; no torch, PCL or Eigen types.
+ *
+ * The reference has no FFI/plugin interface: the seam is the C++ class
+ * ICPPointToPoint (localization/include/localization/icp_point_to_point.h:41-136), the
+ * free functions of localization/include/localization/point_cloud_processing.hpp:31-92,
+ * the PCL VoxelGrid call (localization/src/global_map_frames_manager.cpp:142-146) and,
+ * in the Python twin, three Open3D calls (localization_python/localization_python/
+ * localization_node.py:47,222-225,233-237).  Each entry point below cites what it
+ * replaces.  INTEGRATION.md shows the reference-side bindings.
+ *
+ * Conventions
+ *   - 4x4 matrices: ROW-MAJOR arrays of 16 (Eigen::Matrix4f in the reference is
+ *     column-major: pass M.transpose().data() or use include/localization adapters).
+ *   - Point clouds: AoS xyz float32 triplets (pcl::PointXYZ minus its padding).
+ *   - Every call returns sf_status (0 = ok, < 0 = infrastructure error; text from
+ *     sf_last_error()).  Algorithmic "no lock" is NOT an error: it is reported exactly
+ *     like the reference, in sf_icp_result (initial transform, error 1e6, iterations 0,
+ *     converged 0 — icp_point_to_point.cpp:196-200, icp_point_to_point.h:28-39).
+ *   - Not thread-safe: one sf_ctx per host thread (the reference is single-threaded,
+ *     localization/src/main.cpp:18).  One HIP stream per context; calls that return
+ *     data to the host synchronise that stream, all others only enqueue.
+ *   - There is NO CPU fallback: without a HIP device sf_ctx_create fails.
+ */
+#ifndef SLAMFUSION_H
+#define SLAMFUSION_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_VERSION 100
+
+typedef enum {
+    SF_OK = 0,
+    SF_ERR_INVALID = -1,  /* bad argument                                    */
+    SF_ERR_HIP = -2,      /* HIP runtime failure (message has the hipError)   */
+    SF_ERR_NOMEM = -3,
+    SF_ERR_STATE = -4,    /* call order (e.g. align before set_source)        */
+    SF_ERR_OVERFLOW = -5  /* index space too large for the requested grid     */
+} sf_status;
+
+typedef struct sf_ctx sf_ctx;
+typedef struct sf_cloud sf_cloud;
+typedef struct sf_map sf_map;
+typedef struct sf_icp sf_icp;
+
+int sf_version(void);
+const char *sf_last_error(void);
+
+/* ------------------------------------------------------------------ context */
+/* One context = one device + one stream.  stream == NULL creates a private stream;
+ * otherwise the caller's hipStream_t is used (e.g. a torch ExternalStream) and not owned. */
+int sf_ctx_create(int device_id, void *hip_stream, sf_ctx **out);
+void sf_ctx_destroy(sf_ctx *ctx);
+void *sf_ctx_stream(sf_ctx *ctx);
+int sf_ctx_synchronize(sf_ctx *ctx);
+int sf_ctx_device_name(sf_ctx *ctx, char *buf, int cap);
+
+/* ------------------------------------------------------------------ clouds (device point sets) */
+/* a7: setSourcePointCloud / convertPclToEigen upload — icp_point_to_point.cpp:44-47,86-97 */
+int sf_cloud_create(sf_ctx *ctx, sf_cloud **out);
+void sf_cloud_destroy(sf_cloud *c);
+int sf_cloud_upload(sf_cloud *c, const float *xyz, int64_t n);
+int sf_cloud_upload_f64(sf_cloud *c, const double *xyz, int64_t n); /* rounds to f32 */
+int sf_cloud_from_device(sf_cloud *c, const void *d_xyz, int64_t n); /* device-to-device copy */
+int sf_cloud_size(sf_cloud *c, int64_t *n);
+int sf_cloud_download(sf_cloud *c, float *xyz, int64_t cap, int64_t *n);
+int sf_cloud_copy(sf_cloud *dst, sf_cloud *src);
+/* a1: applyUniformSubsample — point_cloud_processing.hpp:55-74 (no-op when n < step) */
+int sf_cloud_subsample(sf_cloud *c, int step);
+/* a2: cropPointCloudThroughRadius — point_cloud_processing.hpp:31-53.  center = T[:3,3];
+ * keeps d2 < (float)(radius*radius).  sorted != 0 reproduces PCL's ascending
+ * (distance, index) output order; sorted == 0 keeps index order (faster). */
+int sf_cloud_crop_radius(sf_cloud *c, const float center[3], double radius, int sorted);
+/* a3: removeFloor — point_cloud_processing.hpp:76-92 (keep z > 0) */
+int sf_cloud_remove_floor(sf_cloud *c);
+/* a19: readFilterPtcRegionPoints — localization_node.py:105-115 (inclusive AABB, NaN skipped) */
+int sf_cloud_crop_aabb(sf_cloud *c, const double lo[3], const double hi[3]);
+/* a20: OrientedBoundingBox crop — localization_node.py:222-225; R row-major 3x3 */
+int sf_cloud_crop_obb(sf_cloud *c, const double center[3], const double R[9], const double extent[3]);
+/* a8: applyTransformation — icp_point_to_point.cpp:99-110 (general affine 3x4, float32,
+ * unfused multiply/add so results are bit-identical to the reference's x86-64 build) */
+int sf_cloud_transform(sf_cloud *c, const float T[16]);
+/* indices (into the cloud before the call) kept by the LAST crop/subsample on this cloud */
+int sf_cloud_last_indices(sf_cloud *c, int32_t *idx, int64_t cap, int64_t *n);
+
+/* a4 / a5: voxel grids.  flavour SF_VOXEL_PCL = pcl::VoxelGrid float32
+ * (global_map_frames_manager.cpp:142-146): int32 linear index, ascending-index output,
+ * on int32 overflow the cloud is left unchanged and *status_flags gets
+ * SF_FLAG_VOXEL_OVERFLOW (PCL warns and returns its input).  SF_VOXEL_O3D = Open3D
+ * voxel_down_sample float64 (localization_node.py:47): origin min_bound - v/2, output
+ * ordered by (i,j,k). */
+#define SF_VOXEL_PCL 0
+#define SF_VOXEL_O3D 1
+#define SF_FLAG_VOXEL_OVERFLOW 1
+int sf_cloud_voxel_downsample(sf_cloud *c, double leaf, int flavour, int *status_flags);
+/* introspection for parity tests: per-input-point voxel ids of the LAST downsample
+ * (PCL: int32 linear index, -1 for non-finite; O3D: int32 i,j,k triplets) and the ids /
+ * float64 means of the output voxels (O3D flavour keeps float64 means). */
+int sf_cloud_voxel_point_ids(sf_cloud *c, int32_t *ids, int64_t cap_values, int64_t *n_values);
+int sf_cloud_voxel_out_ids(sf_cloud *c, int32_t *ids, int64_t cap_values, int64_t *n_values);
+int sf_cloud_voxel_out_means_f64(sf_cloud *c, double *xyz, int64_t cap_points, int64_t *n_points);
+
+/* ------------------------------------------------------------------ map (NN index) */
+/* a6: setTargetPointCloud — icp_point_to_point.cpp:49-55.  Instead of a FLANN kd-tree
+ * over a 10 m crop rebuilt every 3 m, the WHOLE map gets one device-resident uniform-grid
+ * index (cell size `cell`, 0 = automatic); the reference's crop becomes a window. */
+int sf_map_create(sf_ctx *ctx, sf_map **out);
+void sf_map_destroy(sf_map *m);
+int sf_map_build(sf_map *m, sf_cloud *cloud, float cell);
+int sf_map_size(sf_map *m, int64_t *n);
+int sf_map_cell_size(sf_map *m, float *cell, int32_t dims[3]);
+/* window = the reference's map crop, applied as a predicate inside the search:
+ * sphere: d2(center,p) < (float)(radius*radius) like cropPointCloudThroughRadius
+ * (localization_node.cpp:302); obb: like localization_node.py:222-225; none: whole map */
+int sf_map_window_none(sf_map *m);
+int sf_map_window_sphere(sf_map *m, const float center[3], double radius);
+int sf_map_window_obb(sf_map *m, const double center[3], const double R[9], const double extent[3]);
+/* extension x2 (no reference code): PCA normals from neighbours within `radius` */
+int sf_map_estimate_normals(sf_map *m, float radius);
+int sf_map_set_normals(sf_map *m, const float *normals, int64_t n); /* original point order */
+int sf_map_download_normals(sf_map *m, float *normals, int32_t *n_neighbors, int64_t cap, int64_t *n);
+/* raw exact 1-NN (a9 without the threshold): idx in ORIGINAL point order, d2 squared
+ * float32 summed x,y,z like FLANN L2_Simple; idx = -1 if nothing within max_d2. */
+int sf_map_nn(sf_map *m, const float *queries, int64_t n, float max_d2, int32_t *idx, float *d2);
+
+/* ------------------------------------------------------------------ ICP */
+/* a13: ICPResult — icp_point_to_point.h:28-39 (+ float64 and diagnostics) */
+typedef struct {
+    float T[16];        /* transformation (row-major)                               */
+    float error;        /* ref_cpp: last_error_ ; o3d/p2plane: inlier_rmse           */
+    int32_t iterations; /* steps applied                                             */
+    int32_t converged;  /* has_converged                                             */
+    int32_t n_corr;     /* correspondences of the last search                        */
+    int32_t n_research; /* correspondence searches performed                         */
+    int32_t flags;      /* SF_ICP_FLAG_*                                             */
+    double fitness;     /* o3d/p2plane: n_corr / n_source                            */
+    double rmse;        /* o3d/p2plane                                               */
+    double T64[16];     /* same transformation before rounding to float             */
+} sf_icp_result;
+#define SF_ICP_FLAG_FEW_CORR 1   /* < 10 correspondences: reference returns the initial T */
+#define SF_ICP_FLAG_SINGULAR 2   /* p2plane normal equations not positive definite       */
+
+/* modes: REF_CPP = ICPPointToPoint::calculateAlignment (icp_point_to_point.cpp:185-254,
+ * lazy re-search, d2 < max_correspondence_dist quirk of :70);  O3D_P2P = Open3D
+ * registration_icp point-to-point as called at localization_node.py:233-237;
+ * P2PLANE = extension x1, Gauss-Newton, exactly num_iterations iterations. */
+#define SF_ICP_REF_CPP 0
+#define SF_ICP_O3D_P2P 1
+#define SF_ICP_P2PLANE 2
+
+/* ctor — icp_point_to_point.h:49 / icp_point_to_point.cpp:3-12 */
+int sf_icp_create(sf_ctx *ctx, float max_correspondence_dist, int num_iterations,
+                  float acceptable_mean_error, float transformation_epsilon, sf_icp **out);
+void sf_icp_destroy(sf_icp *icp);
+/* setters — icp_point_to_point.cpp:14-42 */
+int sf_icp_set_max_correspondence_dist(sf_icp *icp, float v);
+int sf_icp_set_num_iterations(sf_icp *icp, int v);
+int sf_icp_set_transformation_epsilon(sf_icp *icp, float v);
+int sf_icp_set_acceptable_mean_error(sf_icp *icp, float v);
+int sf_icp_set_initial_transformation(sf_icp *icp, const float T[16]);
+int sf_icp_set_initial_transformation_f64(sf_icp *icp, const double T[16]);
+int sf_icp_set_debug_mode(sf_icp *icp, int on);
+/* setSourcePointCloud — icp_point_to_point.cpp:44-47 (copies; caller keeps its cloud) */
+int sf_icp_set_source(sf_icp *icp, const float *xyz, int64_t n);
+int sf_icp_set_source_cloud(sf_icp *icp, sf_cloud *cloud);
+/* setTargetPointCloud — icp_point_to_point.cpp:49-55: either index a cloud privately
+ * (reference semantics) or share a prebuilt whole-map index (no copy, no rebuild). */
+int sf_icp_set_target(sf_icp *icp, const float *xyz, int64_t n);
+int sf_icp_set_target_map(sf_icp *icp, sf_map *map);
+/* calculateAlignment — icp_point_to_point.cpp:185-254 */
+int sf_icp_align(sf_icp *icp, int mode, sf_icp_result *out);
+
+/* batched throughput form: `batch` scans of n_per_scan points each (xyz contiguous,
+ * scan-major), one initial transform per scan (inits = batch*16 doubles, NULL = identity),
+ * all registered concurrently against the same target map in ONE kernel sequence. */
+int sf_icp_set_source_batch(sf_icp *icp, const float *xyz, int64_t n_per_scan, int batch);
+int sf_icp_set_source_batch_device(sf_icp *icp, const void *d_xyz, int64_t n_per_scan, int batch);
+int sf_icp_set_initial_batch_f64(sf_icp *icp, const double *inits);
+int sf_icp_align_batch(sf_icp *icp, int mode, sf_icp_result *out /* batch entries */);
+/* enqueue only (no host sync); results fetched later */
+int sf_icp_align_batch_async(sf_icp *icp, int mode);
+int sf_icp_fetch_results(sf_icp *icp, sf_icp_result *out);
+int sf_icp_use_graph(sf_icp *icp, int on); /* replay the launch sequence as a hipGraph */
+
+/* multi-GPU (map tile-sharded along x with halo): this rank only
+ * accumulates queries whose TRANSFORMED x lies in [x_lo, x_hi); per iteration
+ *   sf_icp_step_begin  -> NN + partial normal equations into the exchange buffer
+ *   (caller all-reduces sf_icp_exchange_ptr over RCCL on sf_ctx_stream)
+ *   sf_icp_step_end    -> identical solve on every rank
+ * iteration k of n_total; first=1 resets the state to the initial transforms. */
+int sf_icp_set_shard(sf_icp *icp, float x_lo, float x_hi);
+int sf_icp_set_exchange_buffer(sf_icp *icp, void *d_buf, int64_t nbytes); /* optional: caller-owned (torch tensor) */
+void *sf_icp_exchange_ptr(sf_icp *icp, int64_t *nbytes);
+int sf_icp_step_begin(sf_icp *icp, int mode, int first);
+int sf_icp_step_end(sf_icp *icp, int mode, int last);
+
+/* profiling: wraps every NN kernel of the following aligns in hipEvents on the context
+ * stream; sf_icp_profile_read returns launches and summed milliseconds since enabling. */
+int sf_icp_profile_enable(sf_icp *icp, int on);
+int sf_icp_profile_read(sf_icp *icp, int64_t *nn_launches, double *nn_ms_total);
+
+/* ------------------------------------------------------------------ pose fusion (host, float32 like the reference) */
+/* a14: computePosePredictionFromOdometry — localization_node.cpp:89-110 */
+void sf_fusion_quat_to_pose(const double q_wxyz[4], const double t[3], float T[16]);
+void sf_fusion_odom_prediction(const float map_T_sensor[16], const float odom_T_prev[16],
+                               const float odom_T_cur[16], float out[16]);
+/* a15: compass callback :64-76, UTM::LLtoUTM geo_lib.hpp:38-83, getClosestAltitude
+ * global_map_frames_manager.cpp:69-91, computeGpsCoarsePoseInMapFrame :112-128 */
+float sf_fusion_compass_to_yaw(double compass_deg);
+void sf_fusion_ll_to_utm(double lat, double lon, double *northing, double *easting);
+float sf_fusion_closest_altitude(const double *table_lat_lon_alt, int rows, double lat, double lon);
+void sf_fusion_gps_pose(const double map_T_global[16], float yaw, double lat, double lon,
+                        float table_alt, float out[16]);
+/* a16: computePoseGainsFromCovarianceMatrices — localization_node.cpp:151-179 */
+void sf_fusion_pose_gains(const double gps_cov[9], const double odom_cov[36], int fixed,
+                          float *odom_gain, float *gps_gain);
+/* a17: prior blend — localization_node.cpp:329 */
+void sf_fusion_blend(float g_odom, const float T_odom[16], float g_gps, const float T_gps[16],
+                     float out[16]);
+/* computeMapTGlobal — global_map_frames_manager.cpp:209-248 */
+void sf_fusion_map_T_global(const double *latlonalt, const float *yaw, int n, double out[16]);
+void sf_fusion_mat4f_inverse(const float A[16], float out[16]);
+void sf_fusion_mat4f_mul(const float A[16], const float B[16], float out[16]);
+/* a18: StochasticFilter — stochastic_filter.cpp:3-27,44-113 */
+typedef struct sf_sfilter sf_sfilter;
+sf_sfilter *sf_sfilter_create(int queue_size, float n_std_dev_threshold);
+void sf_sfilter_destroy(sf_sfilter *f);
+void sf_sfilter_set_maximum_linear_velocity(sf_sfilter *f, float v);
+void sf_sfilter_weights(const sf_sfilter *f, float *w);
+void sf_sfilter_add_pose_to_queue(sf_sfilter *f, const float pose[16]);
+float sf_sfilter_pose_zscore(const sf_sfilter *f, const float prev[16], const float cur[16]);
+void sf_sfilter_apply_gaussian_filter(const sf_sfilter *f, const float prev[16],
+                                      const float cur[16], float out[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

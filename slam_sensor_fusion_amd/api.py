@@ -1,0 +1,539 @@
+"""ctypes binding of libslamfusion.so (include/slamfusion.h) — the product's host side.
+
+There is no CPU fallback: if the HIP library is missing or no device is present every
+entry point raises.  Nothing here imports or calls anything under oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libslamfusion.so")
+
+SF_ICP_REF_CPP, SF_ICP_O3D_P2P, SF_ICP_P2PLANE = 0, 1, 2
+SF_VOXEL_PCL, SF_VOXEL_O3D = 0, 1
+SF_FLAG_VOXEL_OVERFLOW = 1
+SF_ICP_FLAG_FEW_CORR, SF_ICP_FLAG_SINGULAR = 1, 2
+MODES = {"ref_cpp": SF_ICP_REF_CPP, "o3d_p2p": SF_ICP_O3D_P2P, "p2plane": SF_ICP_P2PLANE}
+
+
+class SlamFusionError(RuntimeError):
+    pass
+
+
+class IcpResult(C.Structure):
+    """sf_icp_result (ICPResult of icp_point_to_point.h:28-39 plus diagnostics)."""
+    _fields_ = [("T", C.c_float * 16), ("error", C.c_float), ("iterations", C.c_int32),
+                ("converged", C.c_int32), ("n_corr", C.c_int32), ("n_research", C.c_int32),
+                ("flags", C.c_int32), ("fitness", C.c_double), ("rmse", C.c_double),
+                ("T64", C.c_double * 16)]
+
+    def as_dict(self):
+        return dict(T=np.array(self.T, dtype=np.float32).reshape(4, 4),
+                    T64=np.array(self.T64, dtype=np.float64).reshape(4, 4),
+                    error=float(self.error), iterations=int(self.iterations),
+                    converged=bool(self.converged), n_corr=int(self.n_corr),
+                    n_research=int(self.n_research), flags=int(self.flags),
+                    fitness=float(self.fitness), rmse=float(self.rmse))
+
+
+_lib = None
+
+
+def load_library():
+    """Load libslamfusion.so; fails loudly (no fallback) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlamFusionError(
+            "libslamfusion.so not found at %s — build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.sf_last_error.restype = C.c_char_p
+    lib.sf_ctx_stream.restype = C.c_void_p
+    lib.sf_icp_exchange_ptr.restype = C.c_void_p
+    lib.sf_sfilter_create.restype = C.c_void_p
+    lib.sf_fusion_compass_to_yaw.restype = C.c_float
+    lib.sf_fusion_closest_altitude.restype = C.c_float
+    lib.sf_sfilter_pose_zscore.restype = C.c_float
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise SlamFusionError("libslamfusion error %d: %s" % (rc, load_library().sf_last_error().decode()))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """sf_ctx: one device + one HIP stream (optionally a caller-owned stream)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        _check(self.lib.sf_ctx_create(C.c_int(device), C.c_void_p(stream), C.byref(self.h)))
+
+    def synchronize(self):
+        _check(self.lib.sf_ctx_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.sf_ctx_stream(self.h)
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        _check(self.lib.sf_ctx_device_name(self.h, buf, C.c_int(256)))
+        return buf.value.decode()
+
+    def close(self):
+        if self.h:
+            self.lib.sf_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Cloud:
+    """sf_cloud: device point set with the reference's preprocessing operations."""
+
+    def __init__(self, ctx, xyz=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.h = C.c_void_p()
+        _check(self.lib.sf_cloud_create(ctx.h, C.byref(self.h)))
+        if xyz is not None:
+            self.upload(xyz)
+
+    def upload(self, xyz):
+        xyz = _f32(xyz).reshape(-1, 3)
+        _check(self.lib.sf_cloud_upload(self.h, _p(xyz), C.c_int64(len(xyz))))
+        return self
+
+    def from_device(self, ptr, n):
+        _check(self.lib.sf_cloud_from_device(self.h, C.c_void_p(ptr), C.c_int64(n)))
+        return self
+
+    def __len__(self):
+        n = C.c_int64()
+        _check(self.lib.sf_cloud_size(self.h, C.byref(n)))
+        return n.value
+
+    def download(self):
+        n = len(self)
+        out = np.empty((n, 3), np.float32)
+        _check(self.lib.sf_cloud_download(self.h, _p(out), C.c_int64(n), None))
+        return out
+
+    def copy(self):
+        c = Cloud(self.ctx)
+        _check(self.lib.sf_cloud_copy(c.h, self.h))
+        return c
+
+    def subsample(self, step):                       # applyUniformSubsample
+        _check(self.lib.sf_cloud_subsample(self.h, C.c_int(step)))
+        return self
+
+    def crop_radius(self, center, radius, sorted=False):  # cropPointCloudThroughRadius
+        c = _f32(center)
+        _check(self.lib.sf_cloud_crop_radius(self.h, _p(c), C.c_double(radius), C.c_int(int(sorted))))
+        return self
+
+    def remove_floor(self):                          # removeFloor
+        _check(self.lib.sf_cloud_remove_floor(self.h))
+        return self
+
+    def crop_aabb(self, lo, hi):                     # readFilterPtcRegionPoints
+        lo, hi = _f64(lo), _f64(hi)
+        _check(self.lib.sf_cloud_crop_aabb(self.h, _p(lo), _p(hi)))
+        return self
+
+    def crop_obb(self, center, R, extent):           # OrientedBoundingBox crop
+        c, R, e = _f64(center), _f64(R).reshape(3, 3), _f64(extent)
+        _check(self.lib.sf_cloud_crop_obb(self.h, _p(c), _p(R), _p(e)))
+        return self
+
+    def transform(self, T):                          # applyTransformation
+        T = _f32(T).reshape(16)
+        _check(self.lib.sf_cloud_transform(self.h, _p(T)))
+        return self
+
+    def last_indices(self):
+        n = C.c_int64()
+        cap = 1 << 20
+        while True:
+            out = np.empty(cap, np.int32)
+            rc = self.lib.sf_cloud_last_indices(self.h, _p(out), C.c_int64(cap), C.byref(n))
+            if rc == 0:
+                return out[:n.value].copy()
+            if n.value > cap:
+                cap = n.value
+                continue
+            _check(rc)
+
+    def voxel_downsample(self, leaf=0.1, flavour="pcl"):
+        flags = C.c_int(0)
+        fl = SF_VOXEL_PCL if flavour == "pcl" else SF_VOXEL_O3D
+        _check(self.lib.sf_cloud_voxel_downsample(self.h, C.c_double(leaf), C.c_int(fl), C.byref(flags)))
+        return flags.value
+
+    def _i32(self, fn):
+        n = C.c_int64()
+        fn(self.h, None, C.c_int64(0), C.byref(n))
+        out = np.empty(max(n.value, 1), np.int32)
+        _check(fn(self.h, _p(out), C.c_int64(len(out)), C.byref(n)))
+        return out[:n.value]
+
+    def voxel_point_ids(self):
+        return self._i32(self.lib.sf_cloud_voxel_point_ids)
+
+    def voxel_out_ids(self):
+        return self._i32(self.lib.sf_cloud_voxel_out_ids)
+
+    def voxel_out_means_f64(self):
+        n = C.c_int64()
+        self.lib.sf_cloud_voxel_out_means_f64(self.h, None, C.c_int64(0), C.byref(n))
+        out = np.empty((max(n.value, 1), 3), np.float64)
+        _check(self.lib.sf_cloud_voxel_out_means_f64(self.h, _p(out), C.c_int64(len(out)), C.byref(n)))
+        return out[:n.value]
+
+    def close(self):
+        if self.h:
+            self.lib.sf_cloud_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Map:
+    """sf_map: whole-map uniform-grid NN index (replaces the per-crop FLANN kd-tree)."""
+
+    def __init__(self, ctx, cloud=None, cell=0.0):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.h = C.c_void_p()
+        _check(self.lib.sf_map_create(ctx.h, C.byref(self.h)))
+        if cloud is not None:
+            self.build(cloud, cell)
+
+    def build(self, cloud, cell=0.0):
+        if not isinstance(cloud, Cloud):
+            cloud = Cloud(self.ctx, cloud)
+        _check(self.lib.sf_map_build(self.h, cloud.h, C.c_float(cell)))
+        return self
+
+    def __len__(self):
+        n = C.c_int64()
+        _check(self.lib.sf_map_size(self.h, C.byref(n)))
+        return n.value
+
+    def cell_size(self):
+        cell = C.c_float()
+        dims = (C.c_int32 * 3)()
+        _check(self.lib.sf_map_cell_size(self.h, C.byref(cell), dims))
+        return cell.value, tuple(dims)
+
+    def window_none(self):
+        _check(self.lib.sf_map_window_none(self.h))
+
+    def window_sphere(self, center, radius):
+        c = _f32(center)
+        _check(self.lib.sf_map_window_sphere(self.h, _p(c), C.c_double(radius)))
+
+    def window_obb(self, center, R, extent):
+        c, R, e = _f64(center), _f64(R).reshape(3, 3), _f64(extent)
+        _check(self.lib.sf_map_window_obb(self.h, _p(c), _p(R), _p(e)))
+
+    def estimate_normals(self, radius):
+        _check(self.lib.sf_map_estimate_normals(self.h, C.c_float(radius)))
+
+    def set_normals(self, normals):
+        nrm = _f32(normals).reshape(-1, 3)
+        _check(self.lib.sf_map_set_normals(self.h, _p(nrm), C.c_int64(len(nrm))))
+
+    def download_normals(self):
+        n = len(self)
+        nrm = np.empty((n, 3), np.float32)
+        cnt = np.empty(n, np.int32)
+        _check(self.lib.sf_map_download_normals(self.h, _p(nrm), _p(cnt), C.c_int64(n), None))
+        return nrm, cnt
+
+    def nn(self, queries, max_d2=np.inf):
+        q = _f32(queries).reshape(-1, 3)
+        idx = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.float32)
+        _check(self.lib.sf_map_nn(self.h, _p(q), C.c_int64(len(q)), C.c_float(min(max_d2, 3.0e38)), _p(idx), _p(d2)))
+        return idx, d2
+
+    def close(self):
+        if self.h:
+            self.lib.sf_map_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Icp:
+    """sf_icp: mirrors ICPPointToPoint (icp_point_to_point.h:41-136) setter for setter."""
+
+    def __init__(self, ctx, max_correspondence_dist=0.5, num_iterations=10,
+                 acceptable_mean_error=0.05, transformation_epsilon=1e-5):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.h = C.c_void_p()
+        self._map = None
+        self.batch = 1
+        _check(self.lib.sf_icp_create(ctx.h, C.c_float(max_correspondence_dist), C.c_int(num_iterations),
+                                      C.c_float(acceptable_mean_error), C.c_float(transformation_epsilon),
+                                      C.byref(self.h)))
+
+    def set_max_correspondence_dist(self, v):
+        _check(self.lib.sf_icp_set_max_correspondence_dist(self.h, C.c_float(v)))
+
+    def set_num_iterations(self, v):
+        _check(self.lib.sf_icp_set_num_iterations(self.h, C.c_int(v)))
+
+    def set_transformation_epsilon(self, v):
+        _check(self.lib.sf_icp_set_transformation_epsilon(self.h, C.c_float(v)))
+
+    def set_acceptable_mean_error(self, v):
+        _check(self.lib.sf_icp_set_acceptable_mean_error(self.h, C.c_float(v)))
+
+    def set_debug_mode(self, on):
+        _check(self.lib.sf_icp_set_debug_mode(self.h, C.c_int(int(on))))
+
+    def set_initial_transformation(self, T):
+        T = np.asarray(T)
+        if T.dtype == np.float32:
+            T = _f32(T).reshape(16)
+            _check(self.lib.sf_icp_set_initial_transformation(self.h, _p(T)))
+        else:
+            T = _f64(T).reshape(16)
+            _check(self.lib.sf_icp_set_initial_transformation_f64(self.h, _p(T)))
+
+    def set_source(self, xyz):
+        if isinstance(xyz, Cloud):
+            _check(self.lib.sf_icp_set_source_cloud(self.h, xyz.h))
+        else:
+            xyz = _f32(xyz).reshape(-1, 3)
+            _check(self.lib.sf_icp_set_source(self.h, _p(xyz), C.c_int64(len(xyz))))
+        self.batch = 1
+
+    def set_source_batch(self, xyz):
+        xyz = _f32(xyz)
+        assert xyz.ndim == 3 and xyz.shape[2] == 3
+        _check(self.lib.sf_icp_set_source_batch(self.h, _p(xyz), C.c_int64(xyz.shape[1]), C.c_int(xyz.shape[0])))
+        self.batch = xyz.shape[0]
+
+    def set_source_batch_device(self, ptr, n_per_scan, batch):
+        _check(self.lib.sf_icp_set_source_batch_device(self.h, C.c_void_p(ptr), C.c_int64(n_per_scan), C.c_int(batch)))
+        self.batch = batch
+
+    def set_initial_batch(self, inits=None):
+        if inits is None:
+            _check(self.lib.sf_icp_set_initial_batch_f64(self.h, None))
+        else:
+            inits = _f64(inits).reshape(self.batch, 16)
+            _check(self.lib.sf_icp_set_initial_batch_f64(self.h, _p(inits)))
+
+    def set_target(self, target):
+        if isinstance(target, Map):
+            self._map = target
+            _check(self.lib.sf_icp_set_target_map(self.h, target.h))
+        else:
+            xyz = _f32(target).reshape(-1, 3)
+            _check(self.lib.sf_icp_set_target(self.h, _p(xyz), C.c_int64(len(xyz))))
+
+    def use_graph(self, on=True):
+        _check(self.lib.sf_icp_use_graph(self.h, C.c_int(int(on))))
+
+    def align(self, mode="ref_cpp"):
+        r = IcpResult()
+        _check(self.lib.sf_icp_align(self.h, C.c_int(MODES[mode]), C.byref(r)))
+        return r.as_dict()
+
+    def align_batch(self, mode="p2plane"):
+        arr = (IcpResult * self.batch)()
+        _check(self.lib.sf_icp_align_batch(self.h, C.c_int(MODES[mode]), arr))
+        return [r.as_dict() for r in arr]
+
+    def align_batch_async(self, mode="p2plane"):
+        _check(self.lib.sf_icp_align_batch_async(self.h, C.c_int(MODES[mode])))
+
+    def fetch_results(self):
+        arr = (IcpResult * self.batch)()
+        _check(self.lib.sf_icp_fetch_results(self.h, arr))
+        return [r.as_dict() for r in arr]
+
+    # multi-GPU stepping
+    def set_shard(self, x_lo, x_hi):
+        _check(self.lib.sf_icp_set_shard(self.h, C.c_float(x_lo), C.c_float(x_hi)))
+
+    def set_exchange_buffer(self, ptr, nbytes):
+        _check(self.lib.sf_icp_set_exchange_buffer(self.h, C.c_void_p(ptr), C.c_int64(nbytes)))
+
+    def exchange_ptr(self):
+        n = C.c_int64()
+        p = self.lib.sf_icp_exchange_ptr(self.h, C.byref(n))
+        return p, n.value
+
+    def step_begin(self, mode, first):
+        _check(self.lib.sf_icp_step_begin(self.h, C.c_int(MODES[mode]), C.c_int(int(first))))
+
+    def step_end(self, mode, last):
+        _check(self.lib.sf_icp_step_end(self.h, C.c_int(MODES[mode]), C.c_int(int(last))))
+
+    def profile_enable(self, on=True):
+        _check(self.lib.sf_icp_profile_enable(self.h, C.c_int(int(on))))
+
+    def profile_read(self):
+        n, ms = C.c_int64(), C.c_double()
+        _check(self.lib.sf_icp_profile_read(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def close(self):
+        if self.h:
+            self.lib.sf_icp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ pose fusion (host C++)
+def quat_to_pose(q_wxyz, t):
+    q, t = _f64(q_wxyz), _f64(t)
+    T = np.empty(16, np.float32)
+    load_library().sf_fusion_quat_to_pose(_p(q), _p(t), _p(T))
+    return T.reshape(4, 4)
+
+
+def odom_prediction(map_T_sensor, odom_T_prev, odom_T_cur):
+    a, b, c = (_f32(x).reshape(16) for x in (map_T_sensor, odom_T_prev, odom_T_cur))
+    out = np.empty(16, np.float32)
+    load_library().sf_fusion_odom_prediction(_p(a), _p(b), _p(c), _p(out))
+    return out.reshape(4, 4)
+
+
+def compass_to_yaw(deg):
+    return float(load_library().sf_fusion_compass_to_yaw(C.c_double(deg)))
+
+
+def ll_to_utm(lat, lon):
+    n, e = C.c_double(), C.c_double()
+    load_library().sf_fusion_ll_to_utm(C.c_double(lat), C.c_double(lon), C.byref(n), C.byref(e))
+    return n.value, e.value
+
+
+def closest_altitude(table, lat, lon):
+    table = _f64(table).reshape(-1, 3)
+    return float(load_library().sf_fusion_closest_altitude(_p(table), C.c_int(len(table)), C.c_double(lat), C.c_double(lon)))
+
+
+def gps_pose(map_T_global, yaw, lat, lon, table_alt):
+    M = _f64(map_T_global).reshape(16)
+    out = np.empty(16, np.float32)
+    load_library().sf_fusion_gps_pose(_p(M), C.c_float(yaw), C.c_double(lat), C.c_double(lon), C.c_float(table_alt), _p(out))
+    return out.reshape(4, 4)
+
+
+def pose_gains(gps_cov, odom_cov, fixed=False):
+    g, o = _f64(gps_cov).reshape(9), _f64(odom_cov).reshape(36)
+    a, b = C.c_float(), C.c_float()
+    load_library().sf_fusion_pose_gains(_p(g), _p(o), C.c_int(int(fixed)), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def blend(g_odom, T_odom, g_gps, T_gps):
+    a, b = _f32(T_odom).reshape(16), _f32(T_gps).reshape(16)
+    out = np.empty(16, np.float32)
+    load_library().sf_fusion_blend(C.c_float(g_odom), _p(a), C.c_float(g_gps), _p(b), _p(out))
+    return out.reshape(4, 4)
+
+
+def map_T_global(latlonalt, yaw):
+    l, y = _f64(latlonalt).reshape(-1, 3), _f32(yaw)
+    out = np.empty(16, np.float64)
+    load_library().sf_fusion_map_T_global(_p(l), _p(y), C.c_int(len(l)), _p(out))
+    return out.reshape(4, 4)
+
+
+def mat4f_inverse(A):
+    A = _f32(A).reshape(16)
+    out = np.empty(16, np.float32)
+    load_library().sf_fusion_mat4f_inverse(_p(A), _p(out))
+    return out.reshape(4, 4)
+
+
+def mat4f_mul(A, B):
+    A, B = _f32(A).reshape(16), _f32(B).reshape(16)
+    out = np.empty(16, np.float32)
+    load_library().sf_fusion_mat4f_mul(_p(A), _p(B), _p(out))
+    return out.reshape(4, 4)
+
+
+class StochasticFilter:
+    """sf_sfilter: StochasticFilter of localization/src/stochastic_filter.cpp."""
+
+    def __init__(self, queue_size=10, n_std_dev_threshold=1.0):
+        self.lib = load_library()
+        self.q = queue_size
+        self.h = C.c_void_p(self.lib.sf_sfilter_create(C.c_int(queue_size), C.c_float(n_std_dev_threshold)))
+        if not self.h:
+            raise SlamFusionError("sf_sfilter_create failed")
+
+    def setMaximumLinearVelocity(self, v):
+        self.lib.sf_sfilter_set_maximum_linear_velocity(self.h, C.c_float(v))
+
+    def weights(self):
+        w = np.empty(self.q, np.float32)
+        self.lib.sf_sfilter_weights(self.h, _p(w))
+        return w
+
+    def addPoseToQueue(self, pose):
+        p = _f32(pose).reshape(16)
+        self.lib.sf_sfilter_add_pose_to_queue(self.h, _p(p))
+
+    def computePoseZScore(self, prev, cur):
+        a, b = _f32(prev).reshape(16), _f32(cur).reshape(16)
+        return float(self.lib.sf_sfilter_pose_zscore(self.h, _p(a), _p(b)))
+
+    def applyGaussianFilterToCurrentPose(self, prev, cur):
+        a, b = _f32(prev).reshape(16), _f32(cur).reshape(16)
+        out = np.empty(16, np.float32)
+        self.lib.sf_sfilter_apply_gaussian_filter(self.h, _p(a), _p(b), _p(out))
+        return out.reshape(4, 4)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.sf_sfilter_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

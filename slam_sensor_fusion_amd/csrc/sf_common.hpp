@@ -1,0 +1,140 @@
+// sf_common.hpp — internals shared by the libslamfusion translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "slamfusion.h"
+
+namespace sf {
+
+void set_error(const char *fmt, ...);
+
+#define SF_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            sf::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,    \
+                          __LINE__);                                                          \
+            return SF_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+#define SF_CHECK(cond, code, ...)                                                             \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            sf::set_error(__VA_ARGS__);                                                       \
+            return code;                                                                      \
+        }                                                                                     \
+    } while (0)
+
+#define SF_TRY(expr)                                                                          \
+    do {                                                                                      \
+        int rc_ = (expr);                                                                     \
+        if (rc_ != SF_OK) return rc_;                                                         \
+    } while (0)
+
+// growable device buffer (never shrinks: keeps graph-captured pointers stable)
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SF_OK;
+        if (p) {
+            hipError_t e = hipFree(p);
+            (void)e;
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes + (bytes >> 3) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            p = nullptr;
+            return SF_ERR_NOMEM;
+        }
+        cap = want;
+        return SF_OK;
+    }
+    void release()
+    {
+        if (p) {
+            hipError_t e = hipFree(p);
+            (void)e;
+        }
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+} // namespace sf
+
+struct sf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipDeviceProp_t prop;
+    sf::DevBuf scratch;   // rocPRIM temporary storage
+    sf::DevBuf scratch2;  // block counts / small reductions
+    void *h_pinned = nullptr; // small pinned staging (4 KiB)
+};
+
+// AoS xyz float32 point set on the device
+struct sf_cloud {
+    sf_ctx *ctx = nullptr;
+    sf::DevBuf xyz;       // float[n][3]
+    int64_t n = 0;
+    sf::DevBuf last_idx;  // int32 indices kept by the last crop/subsample
+    int64_t n_last_idx = -1;
+    // voxel introspection (parity tests)
+    sf::DevBuf vox_point_ids; int64_t n_vox_point_vals = 0;
+    sf::DevBuf vox_out_ids;   int64_t n_vox_out_vals = 0;
+    sf::DevBuf vox_out_means; int64_t n_vox_out_pts = 0; // float64 means (O3D flavour)
+};
+
+// window predicate applied inside the NN search (the reference's map crop)
+struct SfWindow {
+    int kind;          // 0 none, 1 sphere, 2 obb
+    float c[3];        // sphere centre
+    float r2;          // sphere radius^2 (float, like FLANN)
+    double oc[3];      // obb centre
+    double oR[9];      // obb axes (columns), row-major
+    double ohalf[3];   // obb half extents
+};
+
+struct SfGrid {
+    float org[3];      // grid origin (min corner)
+    float inv_h;       // 1 / cell
+    float h;           // cell size
+    int dim[3];        // cells per axis
+    const uint32_t *cell_start; // [ncell + 1]
+    const float4 *pts;          // sorted by cell: x, y, z, bitcast(original index)
+    const float4 *nrm;          // sorted normals (w = neighbour count) or nullptr
+    int64_t n;
+};
+
+struct sf_map {
+    sf_ctx *ctx = nullptr;
+    sf::DevBuf pts4, nrm4, cell_start, keys, vals, keys2, vals2, inv_perm;
+    int64_t n = 0;
+    bool built = false, has_normals = false;
+    SfGrid grid{};
+    SfWindow window{};
+};
+
+namespace sf {
+// device-side helpers implemented in sf_cloud.hip, used across TUs
+int compact_cloud(sf_cloud *c, const uint8_t *d_flags);
+int ensure_scratch(sf_ctx *ctx, size_t bytes);
+struct MinMaxHost { float mn[3], mx[3]; int64_t n_finite; };
+// min/max over the finite points of a device AoS cloud (synchronises the stream)
+int cloud_minmax(sf_ctx *ctx, const float *d_xyz, int64_t n, MinMaxHost *out);
+} // namespace sf

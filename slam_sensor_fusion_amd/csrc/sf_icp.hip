@@ -1,0 +1,1047 @@
+// sf_icp.hip — ICP on the device (gfx950): fused transform + exact 1-NN + normal-equation
+// accumulation, fixed-order reduction, on-device solve and loop control.
+//
+// Replaces ICPPointToPoint::calculateAlignment and its helpers
+// (localization/src/icp_point_to_point.cpp:57-84,99-170,185-254) and the Open3D
+// registration_icp call of localization_python/localization_python/localization_node.py:
+// 233-237; adds the point-to-plane Gauss-Newton extension.
+//
+// Per iteration (O3D_P2P / P2PLANE):
+//   k_nn_red        one lane per source point: s = T*x0 (float64), exact grid 1-NN of
+//                   float32(s), per-pair contribution accumulated in float64 registers,
+//                   wave64 xor-shuffle reduce -> LDS across the 4 waves -> one partial
+//                   record per workgroup in a slab (no float atomics: bitwise reproducible)
+//   k_reduce_solve  one workgroup per scan: fixed-order sum of the slab, then one lane
+//                   solves (3x3 Jacobi SVD Kabsch / 6x6 LDL^T), composes T and updates the
+//                   convergence flags in device memory — no host round trip per iteration.
+// REF_CPP keeps the reference's data-dependent control flow (lazy re-search, shrinking
+// source set, float32 point updates) with device-side flags; kernels whose phase is not
+// active return immediately, so the launch list is static and graph-capturable.
+#include "sf_common.hpp"
+#include "sf_nn.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int BLK = 256;
+constexpr int NREC_P2P = 17;
+constexpr int NREC_PLANE = 30;
+constexpr int REC_STRIDE = 32; // doubles per scan in the exchange buffer
+
+struct IcpState {
+    double T[16];
+    double rec[REC_STRIDE];
+    double fitness, rmse, prev_fitness, prev_rmse;
+    float last_error, err_pending;
+    float step[12];
+    int step_pending;
+    int iterations, done, research, n_corr, n_research, flags, converged;
+};
+
+struct IcpParams {
+    float max_corr;   // reference: compared against d2 directly (icp_point_to_point.cpp:70)
+    float accept;
+    float eps;
+    int num_iters;
+};
+
+inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)sf::div_up(n > 0 ? n : 1, b); }
+
+// ------------------------------------------------------------------ small device linear algebra (one lane)
+__device__ void mat4_mul(const double A[16], const double B[16], double C[16])
+{
+    double R[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+            R[4 * r + c] = A[4 * r] * B[c] + A[4 * r + 1] * B[4 + c] + A[4 * r + 2] * B[8 + c] + A[4 * r + 3] * B[12 + c];
+    for (int i = 0; i < 16; ++i) C[i] = R[i];
+}
+
+// one-sided Jacobi SVD of a 3x3 (row-major), S descending — stands in for
+// Eigen::JacobiSVD<Matrix3f> at icp_point_to_point.cpp:137 (float64 here)
+__device__ void svd3(const double A[9], double U[9], double S[3], double V[9])
+{
+    double u[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; ++i) u[i] = A[i];
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        int rotated = 0;
+        for (int k = 0; k < 3; ++k) {
+            const int p = k == 2 ? 1 : 0, q = k == 0 ? 1 : 2;
+            double al = 0, be = 0, ga = 0;
+            for (int i = 0; i < 3; ++i) {
+                al += u[3 * i + p] * u[3 * i + p];
+                be += u[3 * i + q] * u[3 * i + q];
+                ga += u[3 * i + p] * u[3 * i + q];
+            }
+            if (fabs(ga) <= DBL_EPSILON * sqrt(al * be) || fabs(ga) < 1e-300) continue;
+            const double zeta = (be - al) / (2 * ga);
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+            const double c = 1 / sqrt(1 + t * t), s = c * t;
+            for (int i = 0; i < 3; ++i) {
+                double a = u[3 * i + p], b = u[3 * i + q];
+                u[3 * i + p] = c * a - s * b;
+                u[3 * i + q] = s * a + c * b;
+                a = v[3 * i + p]; b = v[3 * i + q];
+                v[3 * i + p] = c * a - s * b;
+                v[3 * i + q] = s * a + c * b;
+            }
+            rotated = 1;
+        }
+        if (!rotated) break;
+    }
+    double s[3];
+    int ord[3] = {0, 1, 2};
+    for (int j = 0; j < 3; ++j) s[j] = sqrt(u[j] * u[j] + u[3 + j] * u[3 + j] + u[6 + j] * u[6 + j]);
+    for (int a = 0; a < 2; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (s[ord[b]] > s[ord[a]]) { int tmp = ord[a]; ord[a] = ord[b]; ord[b] = tmp; }
+    for (int j = 0; j < 3; ++j) {
+        const int o = ord[j];
+        S[j] = s[o];
+        for (int i = 0; i < 3; ++i) { U[3 * i + j] = u[3 * i + o]; V[3 * i + j] = v[3 * i + o]; }
+    }
+    const double thr = S[0] * DBL_EPSILON * 8;
+    int rank = 0;
+    for (int j = 0; j < 3; ++j)
+        if (S[j] > thr && S[j] > 0) {
+            for (int i = 0; i < 3; ++i) U[3 * i + j] /= S[j];
+            ++rank;
+        }
+    if (rank == 0) { for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    if (rank == 1) {
+        const double a0 = U[0], a1 = U[3], a2 = U[6];
+        double b0, b1, b2;
+        if (fabs(a0) <= fabs(a1) && fabs(a0) <= fabs(a2)) { b0 = 0; b1 = -a2; b2 = a1; }
+        else if (fabs(a1) <= fabs(a2)) { b0 = -a2; b1 = 0; b2 = a0; }
+        else { b0 = -a1; b1 = a0; b2 = 0; }
+        const double nb = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
+        U[1] = b0 / nb; U[4] = b1 / nb; U[7] = b2 / nb;
+        rank = 2;
+    }
+    if (rank == 2) {
+        U[2] = U[3] * U[7] - U[6] * U[4];
+        U[5] = U[6] * U[1] - U[0] * U[7];
+        U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+}
+
+// Kabsch step (icp_point_to_point.cpp:112-159) from the uncentred sums of the record:
+// rec[0]=n, [1..3]=sum s, [4..6]=sum t, [7..15]=sum s t^T.  H = sum s t^T - n cs ct^T.
+__device__ void kabsch_from_record(const double *rec, double T[16])
+{
+    const double n = rec[0];
+    double cs[3], ct[3], H[9];
+    for (int d = 0; d < 3; ++d) { cs[d] = rec[1 + d] / n; ct[d] = rec[4 + d] / n; }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) H[3 * r + c] = rec[7 + 3 * r + c] - n * cs[r] * ct[c];
+    double U[9], S[3], V[9], R[9];
+    svd3(H, U, S, V);
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                R[3 * r + c] = V[3 * r] * U[3 * c] + V[3 * r + 1] * U[3 * c + 1] + V[3 * r + 2] * U[3 * c + 2];
+        const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+        if (pass == 1 || !(det < 0)) break;
+        V[2] = -V[2]; V[5] = -V[5]; V[8] = -V[8];
+    }
+    for (int i = 0; i < 16; ++i) T[i] = 0;
+    T[15] = 1;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) T[4 * r + c] = R[3 * r + c];
+        T[4 * r + 3] = ct[r] - (R[3 * r] * cs[0] + R[3 * r + 1] * cs[1] + R[3 * r + 2] * cs[2]);
+    }
+}
+
+__device__ int ldlt6(const double A[36], const double b[6], double x[6])
+{
+    double L[36], D[6], y[6];
+    for (int i = 0; i < 36; ++i) L[i] = 0;
+    for (int j = 0; j < 6; ++j) {
+        double d = A[6 * j + j];
+        for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k] * D[k];
+        if (!(fabs(d) > 0) || !isfinite(d)) return -1;
+        D[j] = d;
+        L[6 * j + j] = 1;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = A[6 * i + j];
+            for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k] * D[k];
+            L[6 * i + j] = v / d;
+        }
+    }
+    for (int i = 0; i < 6; ++i) { double v = b[i]; for (int k = 0; k < i; ++k) v -= L[6 * i + k] * y[k]; y[i] = v; }
+    for (int i = 0; i < 6; ++i) y[i] /= D[i];
+    for (int i = 5; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * x[k]; x[i] = v; }
+    return 0;
+}
+
+// R = Rz(v2) Ry(v1) Rx(v0), t = v[3:6] (Open3D TransformVector6dToMatrix4d)
+__device__ void vec6_to_mat4(const double v[6], double T[16])
+{
+    const double ca = cos(v[0]), sa = sin(v[0]), cb = cos(v[1]), sb = sin(v[1]), cg = cos(v[2]), sg = sin(v[2]);
+    const double R[9] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa,
+                         sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa,
+                         -sb, cb * sa, cb * ca};
+    for (int i = 0; i < 16; ++i) T[i] = 0;
+    T[15] = 1;
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T[4 * r + c] = R[3 * r + c]; T[4 * r + 3] = v[3 + r]; }
+}
+
+// ------------------------------------------------------------------ reductions
+template <int NREC>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NREC], double *__restrict__ dst, int nblocks)
+{
+#pragma unroll
+    for (int c = 0; c < NREC; ++c) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc[c] += __shfl_xor(acc[c], off);
+    }
+    __shared__ double s[BLK / 64][NREC];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < NREC; ++c) s[w][c] = acc[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < NREC) {
+        const int c = threadIdx.x;
+        dst[(size_t)c * nblocks] = ((s[0][c] + s[1][c]) + s[2][c]) + s[3][c];
+    }
+}
+
+// sums the slab of one scan in a fixed order into rec[] (shared); all 256 threads take part
+template <int NREC>
+__device__ __forceinline__ void reduce_partials(const double *__restrict__ part, int nblocks, double *rec)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = w; c < NREC; c += BLK / 64) {
+        double v = 0;
+        for (int b = lane; b < nblocks; b += 64) v += part[(size_t)c * nblocks + b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) rec[c] = v;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ helper kernels
+__global__ void k_soa_from_aos(const float *__restrict__ aos, int64_t n, float *__restrict__ x, float *__restrict__ y, float *__restrict__ z)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    x[i] = aos[3 * i]; y[i] = aos[3 * i + 1]; z[i] = aos[3 * i + 2];
+}
+
+__global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict__ inits, int batch)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    IcpState s;
+    for (int i = 0; i < 16; ++i) s.T[i] = inits[16 * b + i];
+    for (int i = 0; i < REC_STRIDE; ++i) s.rec[i] = 0;
+    s.fitness = s.rmse = s.prev_fitness = s.prev_rmse = 0;
+    s.last_error = FLT_MAX; // icp_point_to_point.cpp:205
+    s.err_pending = 0;
+    for (int i = 0; i < 12; ++i) s.step[i] = 0;
+    s.step_pending = 0;
+    s.iterations = s.done = s.research = s.n_corr = s.n_research = s.flags = s.converged = 0;
+    st[b] = s;
+}
+
+// ------------------------------------------------------------------ fused transform + NN + accumulate
+// MODE 1: point-to-point record (17):  n, sum s[3], sum t[3], sum s t^T[9], sum d2
+// MODE 2: point-to-plane record (30):  n, sum r^2, JtJ upper[21], Jtr[6], sum d2
+template <int MODE, bool WINDOW, bool SHARD>
+__global__ __launch_bounds__(BLK) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
+                                                int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks)
+{
+    constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
+    const int b = blockIdx.y;
+    const IcpState *S = st + b;
+    if (S->done) return;
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = S->T[i];
+    double acc[NREC];
+#pragma unroll
+    for (int c = 0; c < NREC; ++c) acc[c] = 0.0;
+    const size_t base = (size_t)b * n;
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += nblocks * BLK) {
+        const double x0 = X0x[base + i], y0 = X0y[base + i], z0 = X0z[base + i];
+        const double sx = T[0] * x0 + T[1] * y0 + T[2] * z0 + T[3];
+        const double sy = T[4] * x0 + T[5] * y0 + T[6] * z0 + T[7];
+        const double sz = T[8] * x0 + T[9] * y0 + T[10] * z0 + T[11];
+        const float qx = (float)sx, qy = (float)sy, qz = (float)sz;
+        if (SHARD && !(qx >= xlo && qx < xhi)) continue;
+        const sf::NNHit hit = sf::nn_search<WINDOW>(g, w, qx, qy, qz, thr);
+        if (hit.j < 0) continue;
+        const double tx = hit.p.x, ty = hit.p.y, tz = hit.p.z;
+        const double ex = sx - tx, ey = sy - ty, ez = sz - tz;
+        const double d2 = ex * ex + ey * ey + ez * ez;
+        if (MODE == 1) {
+            acc[0] += 1.0;
+            acc[1] += sx; acc[2] += sy; acc[3] += sz;
+            acc[4] += tx; acc[5] += ty; acc[6] += tz;
+            acc[7] += sx * tx; acc[8] += sx * ty; acc[9] += sx * tz;
+            acc[10] += sy * tx; acc[11] += sy * ty; acc[12] += sy * tz;
+            acc[13] += sz * tx; acc[14] += sz * ty; acc[15] += sz * tz;
+            acc[16] += d2;
+        } else {
+            const float4 nf = g.nrm[hit.j];
+            const double nx = nf.x, ny = nf.y, nz = nf.z;
+            const double r = ex * nx + ey * ny + ez * nz;
+            double J[6] = {sy * nz - sz * ny, sz * nx - sx * nz, sx * ny - sy * nx, nx, ny, nz};
+            acc[0] += 1.0;
+            acc[1] += r * r;
+            int k = 2;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int c = a; c < 6; ++c) { acc[k] += J[a] * J[c]; ++k; }
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[23 + a] += J[a] * r;
+            acc[29] += d2;
+        }
+    }
+    block_reduce_store<NREC>(acc, partials + ((size_t)b * NREC) * nblocks + blockIdx.x, nblocks);
+}
+
+// ------------------------------------------------------------------ solves (thread 0 of the scan's workgroup)
+// Open3D RegistrationICP loop body after a correspondence search (k-th search, K = max_iteration)
+__device__ void solve_o3d(IcpState *S, const double *rec, int n_src, int k, int K)
+{
+    const double n = rec[0];
+    const double fitness = n_src > 0 ? n / (double)n_src : 0.0;
+    const double rmse = n > 0 ? sqrt(rec[16] / n) : 0.0;
+    S->fitness = fitness;
+    S->rmse = rmse;
+    S->n_corr = (int)n;
+    S->n_research += 1;
+    if (k > 0 && fabs(S->prev_fitness - fitness) < 1e-6 && fabs(S->prev_rmse - rmse) < 1e-6) {
+        S->converged = 1;
+        S->done = 1;
+        return;
+    }
+    if (k >= K) { S->done = 1; return; }
+    if (n > 0) {
+        double upd[16];
+        kabsch_from_record(rec, upd);
+        mat4_mul(upd, S->T, S->T);
+    }
+    S->iterations += 1;
+    S->prev_fitness = fitness;
+    S->prev_rmse = rmse;
+}
+
+__device__ void solve_plane(IcpState *S, const double *rec, int n_src, int K)
+{
+    const double n = rec[0];
+    S->fitness = n_src > 0 ? n / (double)n_src : 0.0;
+    S->rmse = n > 0 ? sqrt(rec[29] / n) : 0.0;
+    S->n_corr = (int)n;
+    S->n_research += 1;
+    double A[36], rhs[6], x[6];
+    int k = 2;
+    for (int a = 0; a < 6; ++a)
+        for (int c = a; c < 6; ++c) { A[6 * a + c] = rec[k]; A[6 * c + a] = rec[k]; ++k; }
+    for (int a = 0; a < 6; ++a) rhs[a] = -rec[23 + a];
+    if (n < 6 || ldlt6(A, rhs, x) != 0) {
+        S->flags |= SF_ICP_FLAG_SINGULAR;
+        S->done = 1;
+        return;
+    }
+    double upd[16];
+    vec6_to_mat4(x, upd);
+    mat4_mul(upd, S->T, S->T);
+    S->iterations += 1;
+    if (S->iterations >= K) { S->converged = 1; S->done = 1; }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BLK) void k_reduce_solve(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, int n_src, int k, int K)
+{
+    constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
+    const int b = blockIdx.x;
+    IcpState *S = st + b;
+    if (S->done) return;
+    __shared__ double rec[REC_STRIDE];
+    reduce_partials<NREC>(partials + ((size_t)b * NREC) * nblocks, nblocks, rec);
+    if (threadIdx.x == 0) {
+        for (int c = 0; c < NREC; ++c) S->rec[c] = rec[c];
+        if (MODE == 1) solve_o3d(S, rec, n_src, k, K);
+        else solve_plane(S, rec, n_src, K);
+    }
+}
+
+// multi-GPU split: reduce into the exchange buffer, all-reduce outside, then solve
+template <int MODE>
+__global__ __launch_bounds__(BLK) void k_reduce_only(const IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, double *__restrict__ xchg)
+{
+    constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
+    const int b = blockIdx.x;
+    __shared__ double rec[REC_STRIDE];
+    if (st[b].done) { // keep the all-reduce shape: contribute zeros
+        if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = 0.0;
+        return;
+    }
+    reduce_partials<NREC>(partials + ((size_t)b * NREC) * nblocks, nblocks, rec);
+    if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = threadIdx.x < NREC ? rec[threadIdx.x] : 0.0;
+}
+
+template <int MODE>
+__global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict__ xchg, int n_src, int k, int K, int batch)
+{
+    constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    IcpState *S = st + b;
+    if (S->done) return;
+    double rec[REC_STRIDE];
+    for (int c = 0; c < NREC; ++c) { rec[c] = xchg[(size_t)b * REC_STRIDE + c]; S->rec[c] = rec[c]; }
+    if (MODE == 1) solve_o3d(S, rec, n_src, k, K);
+    else solve_plane(S, rec, n_src, K);
+}
+
+// ------------------------------------------------------------------ REF_CPP mode
+// X <- init * X0 in float32, unfused, exactly icp_point_to_point.cpp:99-110,191-192
+__global__ void k_ref_init(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n, const IcpState *__restrict__ st,
+                           float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz, int32_t *__restrict__ corr)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const IcpState *S = st + b;
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = (float)S->T[k];
+    const size_t o = (size_t)b * n + i;
+    const float x = X0x[o], y = X0y[o], z = X0z[o];
+    Xx[o] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], x), __fmul_rn(T[1], y)), __fmul_rn(T[2], z)), T[3]);
+    Xy[o] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], x), __fmul_rn(T[5], y)), __fmul_rn(T[6], z)), T[7]);
+    Xz[o] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], x), __fmul_rn(T[9], y)), __fmul_rn(T[10], z)), T[11]);
+    corr[o] = 0; // alive
+}
+
+// sourceTargetCorrespondences (icp_point_to_point.cpp:57-84): points without a match die
+// for good (corr = -1), the survivors remember the sorted position of their target.
+template <bool WINDOW>
+__global__ __launch_bounds__(BLK) void k_ref_nn(SfGrid g, SfWindow w, const float *__restrict__ Xx, const float *__restrict__ Xy, const float *__restrict__ Xz, int n,
+                                                const IcpState *__restrict__ st, float thr, int force, int32_t *__restrict__ corr)
+{
+    const int b = blockIdx.y;
+    const IcpState *S = st + b;
+    if (S->done || !(force || S->research)) return;
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    const size_t o = (size_t)b * n + i;
+    if (corr[o] < 0) return;
+    const sf::NNHit hit = sf::nn_search<WINDOW>(g, w, Xx[o], Xy[o], Xz[o], thr);
+    corr[o] = hit.j;
+}
+
+// optional in-place X <- step * X (float32, unfused), then the 17-scalar record over the
+// live pairs: n, sum s, sum t, sum s t^T, sum ||s - t|| (float32 norm, as
+// calculateErrorMetric icp_point_to_point.cpp:161-170 computes it per pair)
+__global__ __launch_bounds__(BLK) void k_ref_red(const float4 *__restrict__ pts, float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz, int n,
+                                                 const IcpState *__restrict__ st, const int32_t *__restrict__ corr, int apply_step, int only_if_research,
+                                                 double *__restrict__ partials, int nblocks)
+{
+    const int b = blockIdx.y;
+    const IcpState *S = st + b;
+    if (S->done) return;
+    if (only_if_research && !S->research) return;
+    const bool do_step = apply_step && S->step_pending;
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = S->step[k];
+    double acc[NREC_P2P];
+#pragma unroll
+    for (int c = 0; c < NREC_P2P; ++c) acc[c] = 0.0;
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += nblocks * BLK) {
+        const size_t o = (size_t)b * n + i;
+        const int j = corr[o];
+        if (j < 0) continue;
+        float x = Xx[o], y = Xy[o], z = Xz[o];
+        if (do_step) {
+            const float nx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], x), __fmul_rn(T[1], y)), __fmul_rn(T[2], z)), T[3]);
+            const float ny = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], x), __fmul_rn(T[5], y)), __fmul_rn(T[6], z)), T[7]);
+            const float nz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], x), __fmul_rn(T[9], y)), __fmul_rn(T[10], z)), T[11]);
+            x = nx; y = ny; z = nz;
+            Xx[o] = x; Xy[o] = y; Xz[o] = z;
+        }
+        const float4 p = pts[j];
+        const float dx = x - p.x, dy = y - p.y, dz = z - p.z;
+        const float nrm = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz))));
+        const double sx = x, sy = y, sz = z, tx = p.x, ty = p.y, tz = p.z;
+        acc[0] += 1.0;
+        acc[1] += sx; acc[2] += sy; acc[3] += sz;
+        acc[4] += tx; acc[5] += ty; acc[6] += tz;
+        acc[7] += sx * tx; acc[8] += sx * ty; acc[9] += sx * tz;
+        acc[10] += sy * tx; acc[11] += sy * ty; acc[12] += sy * tz;
+        acc[13] += sz * tx; acc[14] += sz * ty; acc[15] += sz * tz;
+        acc[16] += (double)nrm;
+    }
+    block_reduce_store<NREC_P2P>(acc, partials + ((size_t)b * NREC_P2P) * nblocks + blockIdx.x, nblocks);
+}
+
+// step = Kabsch(record); T <- step * T in float32 (icp_point_to_point.cpp:226-228)
+__device__ void ref_take_step(IcpState *S, const double *rec, float error)
+{
+    double upd[16];
+    kabsch_from_record(rec, upd);
+    float sf[16], Tf[16], Tn[16];
+    for (int i = 0; i < 16; ++i) { sf[i] = (float)upd[i]; Tf[i] = (float)S->T[i]; }
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+            Tn[4 * r + c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(sf[4 * r], Tf[c]), __fmul_rn(sf[4 * r + 1], Tf[4 + c])), __fmul_rn(sf[4 * r + 2], Tf[8 + c])),
+                                      __fmul_rn(sf[4 * r + 3], Tf[12 + c]));
+    for (int i = 0; i < 16; ++i) S->T[i] = Tn[i];
+    for (int i = 0; i < 12; ++i) S->step[i] = sf[i];
+    S->step_pending = 1;
+    S->last_error = error;
+    S->iterations += 1;
+}
+
+// phase 0: after the initial search (cpp:195-200); phase 1: top of loop iteration
+// (cpp:209-224); phase 2: after a lazy re-search (cpp:223-226)
+__global__ __launch_bounds__(BLK) void k_ref_decide(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, IcpParams prm, int phase)
+{
+    const int b = blockIdx.x;
+    IcpState *S = st + b;
+    if (S->done) return;
+    if (phase == 2 && !S->research) return;
+    __shared__ double rec[REC_STRIDE];
+    reduce_partials<NREC_P2P>(partials + ((size_t)b * NREC_P2P) * nblocks, nblocks, rec);
+    if (threadIdx.x != 0) return;
+    for (int c = 0; c < NREC_P2P; ++c) S->rec[c] = rec[c];
+    const double n = rec[0];
+    if (phase == 0) {
+        S->n_corr = (int)n;
+        S->n_research = 1;
+        if (n < 10) { S->flags |= SF_ICP_FLAG_FEW_CORR; S->done = 1; }
+        return;
+    }
+    if (phase == 1) {
+        S->step_pending = 0;
+        if (!(n >= 1)) { S->flags |= SF_ICP_FLAG_FEW_CORR; S->done = 1; return; }
+        const float error = (float)(rec[16] / n);
+        if (error < prm.accept) { S->last_error = error; S->done = 1; return; }
+        if (fabsf(S->last_error - error) < prm.eps) { S->research = 1; S->err_pending = error; return; }
+        ref_take_step(S, rec, error);
+        return;
+    }
+    // phase 2: new correspondences are in rec
+    S->research = 0;
+    S->n_corr = (int)n;
+    S->n_research += 1;
+    if (!(n >= 1)) { S->flags |= SF_ICP_FLAG_FEW_CORR; S->done = 1; return; }
+    ref_take_step(S, rec, S->err_pending);
+}
+
+} // namespace
+
+// ==================================================================== host side
+struct sf_icp {
+    sf_ctx *ctx = nullptr;
+    IcpParams prm{};
+    int debug = 0;
+    // source
+    sf::DevBuf X0, X;        // SoA: x[B*n], y[B*n], z[B*n]
+    sf::DevBuf corr;         // int32 [B*n] (REF_CPP)
+    int64_t n = 0;           // points per scan
+    int batch = 0;
+    std::vector<double> inits; // batch * 16
+    bool have_source = false;
+    // target
+    sf_map *map = nullptr;
+    sf_map *own_map = nullptr;
+    sf_cloud *own_cloud = nullptr;
+    // device state
+    sf::DevBuf state, d_inits, partials, xchg_own;
+    void *xchg = nullptr;
+    int64_t xchg_bytes = 0;
+    int nblocks = 0;
+    std::vector<IcpState> h_state;
+    // sharding
+    bool shard = false;
+    float xlo = 0, xhi = 0;
+    int step_k = 0;
+    int last_mode = 0;
+    // graph
+    bool use_graph = false;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_mode = -1, graph_iters = -1, graph_batch = -1, graph_window = -1;
+    int64_t graph_n = -1;
+    const void *graph_map = nullptr;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    int64_t prof_launches = 0;
+    double prof_ms = 0;
+};
+
+namespace {
+
+float *soa(sf::DevBuf &b, int64_t total, int axis) { return b.as<float>() + (size_t)axis * (size_t)total; }
+
+int icp_alloc(sf_icp *icp, int64_t n, int batch)
+{
+    const int64_t total = n * batch;
+    SF_TRY(icp->X0.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
+    SF_TRY(icp->state.reserve(sizeof(IcpState) * (size_t)batch));
+    SF_TRY(icp->d_inits.reserve(sizeof(double) * 16 * (size_t)batch));
+    icp->nblocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, sf::div_up(n, BLK)));
+    SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)NREC_PLANE * (size_t)icp->nblocks * (size_t)batch));
+    SF_TRY(icp->xchg_own.reserve(sizeof(double) * REC_STRIDE * (size_t)batch));
+    if (icp->batch != batch || icp->inits.size() != (size_t)batch * 16) {
+        icp->inits.assign((size_t)batch * 16, 0.0);
+        for (int b = 0; b < batch; ++b)
+            for (int d = 0; d < 4; ++d) icp->inits[(size_t)b * 16 + 5 * d] = 1.0;
+    }
+    icp->n = n;
+    icp->batch = batch;
+    icp->h_state.resize((size_t)batch);
+    return SF_OK;
+}
+
+int icp_set_source_device_aos(sf_icp *icp, const float *d_aos, int64_t n, int batch)
+{
+    SF_TRY(icp_alloc(icp, n, batch));
+    const int64_t total = n * batch;
+    if (total > 0)
+        hipLaunchKernelGGL(k_soa_from_aos, dim3(nblk(total)), dim3(256), 0, icp->ctx->stream, d_aos, total, soa(icp->X0, total, 0), soa(icp->X0, total, 1),
+                           soa(icp->X0, total, 2));
+    SF_HIP(hipGetLastError());
+    icp->have_source = true;
+    return SF_OK;
+}
+
+struct ProfScope {
+    sf_icp *icp;
+    explicit ProfScope(sf_icp *i) : icp(i)
+    {
+        if (!icp->profiling) return;
+        while (icp->ev.size() < icp->ev_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) { icp->profiling = false; return; }
+            icp->ev.push_back(e);
+        }
+        hipError_t e = hipEventRecord(icp->ev[icp->ev_used], icp->ctx->stream);
+        (void)e;
+    }
+    ~ProfScope()
+    {
+        if (!icp->profiling) return;
+        hipError_t e = hipEventRecord(icp->ev[icp->ev_used + 1], icp->ctx->stream);
+        (void)e;
+        icp->ev_used += 2;
+    }
+};
+
+void prof_collect(sf_icp *icp)
+{
+    for (size_t k = 0; k + 1 < icp->ev_used; k += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, icp->ev[k], icp->ev[k + 1]) == hipSuccess) { icp->prof_ms += ms; icp->prof_launches += 1; }
+    }
+    icp->ev_used = 0;
+}
+
+float o3d_thr(const sf_icp *icp) { return (float)((double)icp->prm.max_corr * (double)icp->prm.max_corr); }
+
+template <int MODE>
+void launch_nn_red(sf_icp *icp)
+{
+    sf_map *m = icp->map;
+    const dim3 grid((unsigned)icp->nblocks, (unsigned)icp->batch), blk(BLK);
+    const int64_t total = icp->n * icp->batch;
+    const float *x = soa(icp->X0, total, 0), *y = soa(icp->X0, total, 1), *z = soa(icp->X0, total, 2);
+    const IcpState *st = icp->state.as<IcpState>();
+    double *part = icp->partials.as<double>();
+    const float thr = o3d_thr(icp);
+    hipStream_t s = icp->ctx->stream;
+    ProfScope ps(icp);
+    const bool win = m->window.kind != 0;
+#define SF_LAUNCH_NNRED(W, S)                                                                                                                                    \
+    hipLaunchKernelGGL((k_nn_red<MODE, W, S>), grid, blk, 0, s, m->grid, m->window, x, y, z, (int)icp->n, st, thr, icp->xlo, icp->xhi, part, icp->nblocks)
+    if (win && icp->shard) SF_LAUNCH_NNRED(true, true);
+    else if (win) SF_LAUNCH_NNRED(true, false);
+    else if (icp->shard) SF_LAUNCH_NNRED(false, true);
+    else SF_LAUNCH_NNRED(false, false);
+#undef SF_LAUNCH_NNRED
+}
+
+void launch_state_init(sf_icp *icp)
+{
+    hipStream_t s = icp->ctx->stream;
+    hipError_t e = hipMemcpyAsync(icp->d_inits.p, icp->inits.data(), sizeof(double) * 16 * (size_t)icp->batch, hipMemcpyHostToDevice, s);
+    (void)e;
+    hipLaunchKernelGGL(k_state_init, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), icp->d_inits.as<double>(), icp->batch);
+}
+
+// enqueue the whole alignment (no host synchronisation)
+int enqueue_align(sf_icp *icp, int mode)
+{
+    sf_map *m = icp->map;
+    hipStream_t s = icp->ctx->stream;
+    IcpState *st = icp->state.as<IcpState>();
+    double *part = icp->partials.as<double>();
+    const int K = icp->prm.num_iters;
+    const int B = icp->batch;
+    const int n = (int)icp->n;
+    if (mode == SF_ICP_O3D_P2P) {
+        for (int k = 0; k <= K; ++k) {
+            launch_nn_red<1>(icp);
+            hipLaunchKernelGGL(k_reduce_solve<1>, dim3(B), dim3(BLK), 0, s, st, part, icp->nblocks, n, k, K);
+        }
+    } else if (mode == SF_ICP_P2PLANE) {
+        for (int k = 0; k < K; ++k) {
+            launch_nn_red<2>(icp);
+            hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(BLK), 0, s, st, part, icp->nblocks, n, k, K);
+        }
+    } else {
+        const int64_t total = icp->n * B;
+        SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
+        SF_TRY(icp->corr.reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1)));
+        float *Xx = soa(icp->X, total, 0), *Xy = soa(icp->X, total, 1), *Xz = soa(icp->X, total, 2);
+        int32_t *corr = icp->corr.as<int32_t>();
+        const dim3 gpts(nblk(n), (unsigned)B), gred((unsigned)icp->nblocks, (unsigned)B);
+        const bool win = m->window.kind != 0;
+        const float thr = icp->prm.max_corr; // squared-vs-unsquared quirk, icp_point_to_point.cpp:70
+        auto nn = [&](int force) {
+            ProfScope ps(icp);
+            if (win) hipLaunchKernelGGL(k_ref_nn<true>, gpts, dim3(BLK), 0, s, m->grid, m->window, Xx, Xy, Xz, n, st, thr, force, corr);
+            else hipLaunchKernelGGL(k_ref_nn<false>, gpts, dim3(BLK), 0, s, m->grid, m->window, Xx, Xy, Xz, n, st, thr, force, corr);
+        };
+        auto red = [&](int apply, int only_research) {
+            hipLaunchKernelGGL(k_ref_red, gred, dim3(BLK), 0, s, m->grid.pts, Xx, Xy, Xz, n, st, corr, apply, only_research, part, icp->nblocks);
+        };
+        auto decide = [&](int phase) { hipLaunchKernelGGL(k_ref_decide, dim3(B), dim3(BLK), 0, s, st, part, icp->nblocks, icp->prm, phase); };
+        hipLaunchKernelGGL(k_ref_init, gpts, dim3(BLK), 0, s, soa(icp->X0, total, 0), soa(icp->X0, total, 1), soa(icp->X0, total, 2), n, st, Xx, Xy, Xz, corr);
+        nn(1);
+        red(0, 0);
+        decide(0);
+        for (int i = 0; i < K; ++i) {
+            decide(1);
+            nn(0);
+            red(0, 1);
+            decide(2);
+            if (i + 1 < K) red(1, 0);
+        }
+    }
+    SF_HIP(hipGetLastError());
+    return SF_OK;
+}
+
+int check_ready(sf_icp *icp, int mode)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    SF_CHECK(mode >= 0 && mode <= 2, SF_ERR_INVALID, "unknown mode %d", mode);
+    SF_CHECK(icp->have_source, SF_ERR_STATE, "no source cloud set");
+    SF_CHECK(icp->map && icp->map->built, SF_ERR_STATE, "no target set");
+    SF_CHECK(mode != SF_ICP_P2PLANE || icp->map->has_normals, SF_ERR_STATE, "point-to-plane needs map normals (sf_map_estimate_normals)");
+    SF_CHECK(icp->prm.num_iters >= 0, SF_ERR_INVALID, "negative iteration count");
+    return SF_OK;
+}
+
+void fill_result(const sf_icp *icp, int mode, const IcpState &S, const double *init, sf_icp_result *r)
+{
+    const bool failed = (mode == SF_ICP_REF_CPP) && (S.flags & SF_ICP_FLAG_FEW_CORR) && S.iterations == 0;
+    for (int i = 0; i < 16; ++i) {
+        r->T64[i] = failed ? init[i] : S.T[i];
+        r->T[i] = (float)r->T64[i];
+    }
+    r->iterations = S.iterations;
+    r->n_corr = S.n_corr;
+    r->n_research = S.n_research;
+    r->flags = S.flags;
+    r->fitness = S.fitness;
+    r->rmse = S.rmse;
+    if (mode == SF_ICP_REF_CPP) {
+        // ICPResult defaults (icp_point_to_point.h:28-39) on the < 10 correspondences path
+        r->error = failed ? 1e6f : S.last_error;
+        r->converged = failed ? 0 : (S.last_error < icp->prm.accept);
+    } else {
+        r->error = (float)S.rmse;
+        r->converged = S.converged;
+    }
+}
+
+} // namespace
+
+extern "C" int sf_icp_create(sf_ctx *ctx, float max_correspondence_dist, int num_iterations, float acceptable_mean_error, float transformation_epsilon, sf_icp **out)
+{
+    SF_CHECK(ctx && out, SF_ERR_INVALID, "bad arguments");
+    sf_icp *icp = new (std::nothrow) sf_icp();
+    SF_CHECK(icp, SF_ERR_NOMEM, "out of host memory");
+    icp->ctx = ctx;
+    icp->prm.max_corr = max_correspondence_dist;
+    icp->prm.num_iters = num_iterations;
+    icp->prm.accept = acceptable_mean_error;
+    icp->prm.eps = transformation_epsilon;
+    *out = icp;
+    return SF_OK;
+}
+
+extern "C" void sf_icp_destroy(sf_icp *icp)
+{
+    if (!icp) return;
+    hipError_t e = hipStreamSynchronize(icp->ctx->stream);
+    (void)e;
+    if (icp->graph_exec) { e = hipGraphExecDestroy(icp->graph_exec); (void)e; }
+    for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
+    icp->X0.release(); icp->X.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
+    icp->partials.release(); icp->xchg_own.release();
+    if (icp->own_map) sf_map_destroy(icp->own_map);
+    if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
+    delete icp;
+}
+
+extern "C" int sf_icp_set_max_correspondence_dist(sf_icp *icp, float v) { SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL"); icp->prm.max_corr = v; return SF_OK; }
+extern "C" int sf_icp_set_num_iterations(sf_icp *icp, int v) { SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL"); icp->prm.num_iters = v; return SF_OK; }
+extern "C" int sf_icp_set_transformation_epsilon(sf_icp *icp, float v) { SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL"); icp->prm.eps = v; return SF_OK; }
+extern "C" int sf_icp_set_acceptable_mean_error(sf_icp *icp, float v) { SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL"); icp->prm.accept = v; return SF_OK; }
+extern "C" int sf_icp_set_debug_mode(sf_icp *icp, int on) { SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL"); icp->debug = on; return SF_OK; }
+
+extern "C" int sf_icp_set_initial_transformation(sf_icp *icp, const float T[16])
+{
+    SF_CHECK(icp && T, SF_ERR_INVALID, "bad arguments");
+    if (icp->inits.size() < 16) icp->inits.assign(16, 0.0);
+    for (int i = 0; i < 16; ++i) icp->inits[i] = T[i];
+    return SF_OK;
+}
+
+extern "C" int sf_icp_set_initial_transformation_f64(sf_icp *icp, const double T[16])
+{
+    SF_CHECK(icp && T, SF_ERR_INVALID, "bad arguments");
+    if (icp->inits.size() < 16) icp->inits.assign(16, 0.0);
+    for (int i = 0; i < 16; ++i) icp->inits[i] = T[i];
+    return SF_OK;
+}
+
+extern "C" int sf_icp_set_initial_batch_f64(sf_icp *icp, const double *inits)
+{
+    SF_CHECK(icp && icp->batch > 0, SF_ERR_STATE, "set the source batch first");
+    icp->inits.assign((size_t)icp->batch * 16, 0.0);
+    for (int b = 0; b < icp->batch; ++b)
+        for (int i = 0; i < 16; ++i) icp->inits[(size_t)b * 16 + i] = inits ? inits[(size_t)b * 16 + i] : (i % 5 == 0 ? 1.0 : 0.0);
+    return SF_OK;
+}
+
+extern "C" int sf_icp_set_source_batch(sf_icp *icp, const float *xyz, int64_t n_per_scan, int batch)
+{
+    SF_CHECK(icp && n_per_scan >= 0 && batch >= 1 && (xyz || n_per_scan == 0), SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(n_per_scan * batch < (int64_t)0x7fffffff, SF_ERR_OVERFLOW, "too many source points");
+    SF_HIP(hipSetDevice(icp->ctx->device));
+    std::vector<double> keep = icp->inits;
+    const int64_t total = n_per_scan * batch;
+    sf::DevBuf tmp;
+    SF_TRY(tmp.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
+    if (total > 0) SF_HIP(hipMemcpyAsync(tmp.p, xyz, sizeof(float) * 3 * (size_t)total, hipMemcpyHostToDevice, icp->ctx->stream));
+    int rc = icp_set_source_device_aos(icp, tmp.as<float>(), n_per_scan, batch);
+    hipError_t e = hipStreamSynchronize(icp->ctx->stream);
+    tmp.release();
+    if (rc == SF_OK && e != hipSuccess) { sf::set_error("sync: %s", hipGetErrorString(e)); rc = SF_ERR_HIP; }
+    if (batch == 1 && keep.size() >= 16) icp->inits.assign(keep.begin(), keep.begin() + 16); // setters are order independent
+    return rc;
+}
+
+extern "C" int sf_icp_set_source_batch_device(sf_icp *icp, const void *d_xyz, int64_t n_per_scan, int batch)
+{
+    SF_CHECK(icp && n_per_scan >= 0 && batch >= 1 && (d_xyz || n_per_scan == 0), SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(n_per_scan * batch < (int64_t)0x7fffffff, SF_ERR_OVERFLOW, "too many source points");
+    SF_HIP(hipSetDevice(icp->ctx->device));
+    std::vector<double> keep = icp->inits;
+    int rc = icp_set_source_device_aos(icp, reinterpret_cast<const float *>(d_xyz), n_per_scan, batch);
+    if (batch == 1 && keep.size() >= 16) icp->inits.assign(keep.begin(), keep.begin() + 16);
+    return rc;
+}
+
+extern "C" int sf_icp_set_source(sf_icp *icp, const float *xyz, int64_t n) { return sf_icp_set_source_batch(icp, xyz, n, 1); }
+
+extern "C" int sf_icp_set_source_cloud(sf_icp *icp, sf_cloud *cloud)
+{
+    SF_CHECK(icp && cloud, SF_ERR_INVALID, "bad arguments");
+    return sf_icp_set_source_batch_device(icp, cloud->xyz.p, cloud->n, 1);
+}
+
+extern "C" int sf_icp_set_target_map(sf_icp *icp, sf_map *map)
+{
+    SF_CHECK(icp && map, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(map->built, SF_ERR_STATE, "map not built");
+    icp->map = map;
+    return SF_OK;
+}
+
+extern "C" int sf_icp_set_target(sf_icp *icp, const float *xyz, int64_t n)
+{
+    SF_CHECK(icp && n >= 0 && (xyz || n == 0), SF_ERR_INVALID, "bad arguments");
+    if (!icp->own_cloud) SF_TRY(sf_cloud_create(icp->ctx, &icp->own_cloud));
+    if (!icp->own_map) SF_TRY(sf_map_create(icp->ctx, &icp->own_map));
+    SF_TRY(sf_cloud_upload(icp->own_cloud, xyz, n));
+    SF_TRY(sf_map_build(icp->own_map, icp->own_cloud, 0.0f));
+    icp->map = icp->own_map;
+    return SF_OK;
+}
+
+extern "C" int sf_icp_use_graph(sf_icp *icp, int on)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    icp->use_graph = on != 0;
+    return SF_OK;
+}
+
+extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
+{
+    SF_TRY(check_ready(icp, mode));
+    SF_HIP(hipSetDevice(icp->ctx->device));
+    hipStream_t s = icp->ctx->stream;
+    icp->last_mode = mode;
+    launch_state_init(icp);
+    if (icp->use_graph && !icp->profiling) {
+        const bool hit = icp->graph_exec && icp->graph_mode == mode && icp->graph_iters == icp->prm.num_iters && icp->graph_batch == icp->batch &&
+                         icp->graph_n == icp->n && icp->graph_map == (const void *)icp->map->grid.pts && icp->graph_window == icp->map->window.kind &&
+                         icp->map->window.kind == 0 && !icp->shard;
+        if (!hit) {
+            if (icp->graph_exec) { hipError_t e = hipGraphExecDestroy(icp->graph_exec); (void)e; icp->graph_exec = nullptr; }
+            if (mode == SF_ICP_REF_CPP) { // buffers must exist before capture
+                const int64_t total = icp->n * icp->batch;
+                SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
+                SF_TRY(icp->corr.reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1)));
+            }
+            hipGraph_t graph = nullptr;
+            SF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            int rc = enqueue_align(icp, mode);
+            hipError_t e = hipStreamEndCapture(s, &graph);
+            if (rc != SF_OK) return rc;
+            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            e = hipGraphInstantiate(&icp->graph_exec, graph, nullptr, nullptr, 0);
+            hipError_t e2 = hipGraphDestroy(graph);
+            (void)e2;
+            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+            icp->graph_mode = mode; icp->graph_iters = icp->prm.num_iters; icp->graph_batch = icp->batch; icp->graph_n = icp->n;
+            icp->graph_map = (const void *)icp->map->grid.pts; icp->graph_window = icp->map->window.kind;
+        }
+        SF_HIP(hipGraphLaunch(icp->graph_exec, s));
+        return SF_OK;
+    }
+    return enqueue_align(icp, mode);
+}
+
+extern "C" int sf_icp_fetch_results(sf_icp *icp, sf_icp_result *out)
+{
+    SF_CHECK(icp && out, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(icp->batch > 0, SF_ERR_STATE, "nothing to fetch");
+    hipStream_t s = icp->ctx->stream;
+    SF_HIP(hipMemcpyAsync(icp->h_state.data(), icp->state.p, sizeof(IcpState) * (size_t)icp->batch, hipMemcpyDeviceToHost, s));
+    SF_HIP(hipStreamSynchronize(s));
+    if (icp->profiling) prof_collect(icp);
+    for (int b = 0; b < icp->batch; ++b) fill_result(icp, icp->last_mode, icp->h_state[(size_t)b], &icp->inits[(size_t)b * 16], out + b);
+    return SF_OK;
+}
+
+extern "C" int sf_icp_align_batch(sf_icp *icp, int mode, sf_icp_result *out)
+{
+    SF_CHECK(out, SF_ERR_INVALID, "out is NULL");
+    SF_TRY(sf_icp_align_batch_async(icp, mode));
+    int rc = sf_icp_fetch_results(icp, out);
+    if (rc == SF_OK && icp->debug)
+        for (int b = 0; b < icp->batch; ++b)
+            fprintf(stdout, "[ICP INFO] scan %d: iterations %d, error %g, correspondences %d, converged %d\n", b, out[b].iterations, (double)out[b].error,
+                    out[b].n_corr, out[b].converged);
+    return rc;
+}
+
+extern "C" int sf_icp_align(sf_icp *icp, int mode, sf_icp_result *out)
+{
+    SF_CHECK(icp && icp->batch == 1, SF_ERR_STATE, "sf_icp_align needs a single source scan (use sf_icp_align_batch)");
+    return sf_icp_align_batch(icp, mode, out);
+}
+
+// ------------------------------------------------------------------ multi-GPU stepping
+extern "C" int sf_icp_set_shard(sf_icp *icp, float x_lo, float x_hi)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    icp->shard = x_lo > -INFINITY || x_hi < INFINITY;
+    icp->xlo = x_lo;
+    icp->xhi = x_hi;
+    return SF_OK;
+}
+
+extern "C" int sf_icp_set_exchange_buffer(sf_icp *icp, void *d_buf, int64_t nbytes)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    icp->xchg = d_buf;
+    icp->xchg_bytes = d_buf ? nbytes : 0;
+    return SF_OK;
+}
+
+extern "C" void *sf_icp_exchange_ptr(sf_icp *icp, int64_t *nbytes)
+{
+    if (!icp) return nullptr;
+    const int64_t need = (int64_t)sizeof(double) * REC_STRIDE * std::max(icp->batch, 1);
+    if (nbytes) *nbytes = need;
+    if (icp->xchg && icp->xchg_bytes >= need) return icp->xchg;
+    return icp->xchg_own.p;
+}
+
+extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
+{
+    SF_TRY(check_ready(icp, mode));
+    SF_CHECK(mode != SF_ICP_REF_CPP, SF_ERR_INVALID, "stepping supports O3D_P2P and P2PLANE");
+    SF_HIP(hipSetDevice(icp->ctx->device));
+    icp->last_mode = mode;
+    if (first) { launch_state_init(icp); icp->step_k = 0; }
+    double *x = reinterpret_cast<double *>(sf_icp_exchange_ptr(icp, nullptr));
+    hipStream_t s = icp->ctx->stream;
+    if (mode == SF_ICP_O3D_P2P) {
+        launch_nn_red<1>(icp);
+        hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(BLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), icp->nblocks, x);
+    } else {
+        launch_nn_red<2>(icp);
+        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(BLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), icp->nblocks, x);
+    }
+    SF_HIP(hipGetLastError());
+    return SF_OK;
+}
+
+extern "C" int sf_icp_step_end(sf_icp *icp, int mode, int last)
+{
+    SF_TRY(check_ready(icp, mode));
+    (void)last;
+    const double *x = reinterpret_cast<const double *>(sf_icp_exchange_ptr(icp, nullptr));
+    hipStream_t s = icp->ctx->stream;
+    const int K = icp->prm.num_iters;
+    if (mode == SF_ICP_O3D_P2P)
+        hipLaunchKernelGGL(k_solve_only<1>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, icp->step_k, K, icp->batch);
+    else
+        hipLaunchKernelGGL(k_solve_only<2>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, icp->step_k, K, icp->batch);
+    icp->step_k += 1;
+    SF_HIP(hipGetLastError());
+    return SF_OK;
+}
+
+// ------------------------------------------------------------------ profiling
+extern "C" int sf_icp_profile_enable(sf_icp *icp, int on)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    icp->profiling = on != 0;
+    icp->ev_used = 0;
+    icp->prof_launches = 0;
+    icp->prof_ms = 0;
+    return SF_OK;
+}
+
+extern "C" int sf_icp_profile_read(sf_icp *icp, int64_t *nn_launches, double *nn_ms_total)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    SF_HIP(hipStreamSynchronize(icp->ctx->stream));
+    prof_collect(icp);
+    if (nn_launches) *nn_launches = icp->prof_launches;
+    if (nn_ms_total) *nn_ms_total = icp->prof_ms;
+    return SF_OK;
+}

@@ -1,0 +1,421 @@
+// sf_map.hip — device-resident uniform-grid index over the WHOLE map (gfx950).
+//
+// Replaces ICPPointToPoint::setTargetPointCloud (localization/src/icp_point_to_point.cpp:
+// 49-55: deep copy + FLANN kd-tree over a 10 m crop, rebuilt every 3 m of travel,
+// localization/src/localization_node.cpp:299-305).  The map is indexed once; the crop
+// becomes a window predicate (sf_map_window_*).  Layout in HBM:
+//   pts4[n]       float4  x, y, z, bitcast(original index), sorted by cell id (x fastest)
+//   cell_start[ncell+1] u32  first sorted position of each cell
+//   nrm4[n]       float4  normal xyz + neighbour count (sorted order), optional
+#include "sf_common.hpp"
+#include "sf_nn.hpp"
+
+#include <rocprim/rocprim.hpp>
+#include <cmath>
+
+namespace {
+
+inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)sf::div_up(n > 0 ? n : 1, b); }
+
+struct GridGeom { float org[3]; float inv_h; int dim[3]; uint32_t ncell; };
+
+__global__ void k_cell_keys(const float *__restrict__ xyz, int64_t n, GridGeom g, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    uint32_t key = g.ncell; // non-finite points sort last and are not indexed (PCL drops them too)
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+        int cx = (int)fminf(fmaxf(floorf((x - g.org[0]) * g.inv_h), 0.0f), (float)(g.dim[0] - 1));
+        int cy = (int)fminf(fmaxf(floorf((y - g.org[1]) * g.inv_h), 0.0f), (float)(g.dim[1] - 1));
+        int cz = (int)fminf(fmaxf(floorf((z - g.org[2]) * g.inv_h), 0.0f), (float)(g.dim[2] - 1));
+        key = ((uint32_t)cz * (uint32_t)g.dim[1] + (uint32_t)cy) * (uint32_t)g.dim[0] + (uint32_t)cx;
+    }
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
+}
+
+__global__ void k_gather_sorted(const float *__restrict__ xyz, const uint32_t *__restrict__ vals, int64_t n, float4 *__restrict__ pts4, uint32_t *__restrict__ inv_perm)
+{
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t i = vals[j];
+    pts4[j] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __uint_as_float(i));
+    inv_perm[i] = (uint32_t)j;
+}
+
+// cell_start[c] = first sorted position whose key >= c, for c in [0, ncell]
+__global__ void k_cell_bounds(const uint32_t *__restrict__ keys, int64_t n_valid, uint32_t ncell, uint32_t *__restrict__ cell_start)
+{
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_valid) return;
+    uint32_t k = keys[j];
+    uint32_t prev_next = j == 0 ? 0u : keys[j - 1] + 1u;
+    for (uint32_t c = prev_next; c <= k; ++c) cell_start[c] = (uint32_t)j;
+    if (j == n_valid - 1)
+        for (uint32_t c = k + 1; c <= ncell; ++c) cell_start[c] = (uint32_t)n_valid;
+}
+
+__global__ void k_fill_u32(uint32_t *p, int64_t n, uint32_t v)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+} // namespace
+
+// SfGrid / SfWindow are passed to kernels by value
+namespace {
+template <bool WINDOW>
+__global__ __launch_bounds__(256) void k_map_nn_t(SfGrid g, SfWindow w, const float *__restrict__ q, int64_t n, float thr, int32_t *__restrict__ idx,
+                                                 float *__restrict__ d2)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sf::NNHit hit = sf::nn_search<WINDOW>(g, w, q[3 * i], q[3 * i + 1], q[3 * i + 2], thr);
+    idx[i] = hit.j >= 0 ? (int32_t)__float_as_uint(hit.p.w) : -1;
+    d2[i] = hit.j >= 0 ? hit.d2 : INFINITY;
+}
+} // namespace
+
+extern "C" int sf_map_create(sf_ctx *ctx, sf_map **out)
+{
+    SF_CHECK(ctx && out, SF_ERR_INVALID, "bad arguments");
+    sf_map *m = new (std::nothrow) sf_map();
+    SF_CHECK(m, SF_ERR_NOMEM, "out of host memory");
+    m->ctx = ctx;
+    *out = m;
+    return SF_OK;
+}
+
+extern "C" void sf_map_destroy(sf_map *m)
+{
+    if (!m) return;
+    hipError_t e = hipStreamSynchronize(m->ctx->stream);
+    (void)e;
+    m->pts4.release(); m->nrm4.release(); m->cell_start.release(); m->keys.release(); m->vals.release();
+    m->keys2.release(); m->vals2.release(); m->inv_perm.release();
+    delete m;
+}
+
+extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
+{
+    SF_CHECK(m && cloud, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(cloud->n < (int64_t)0x7fffffff, SF_ERR_OVERFLOW, "map too large for 32-bit point ids");
+    sf_ctx *ctx = m->ctx;
+    SF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t n = cloud->n;
+    m->built = false;
+    m->has_normals = false;
+    m->n = 0;
+    m->window.kind = 0;
+    const float *xyz = cloud->xyz.as<float>();
+
+    // 1. bounds of the finite points
+    sf::MinMaxHost mm;
+    SF_TRY(sf::cloud_minmax(ctx, xyz, n, &mm));
+    const int64_t n_valid = mm.n_finite;
+
+    // 2. geometry: automatic cell ~ 1.5 points per cell, clamped; grow until it fits u32
+    double ext[3];
+    for (int d = 0; d < 3; ++d) ext[d] = n_valid > 0 ? (double)mm.mx[d] - (double)mm.mn[d] : 0.0;
+    double h = cell;
+    if (!(h > 0)) {
+        double vol = std::max(ext[0], 1e-3) * std::max(ext[1], 1e-3) * std::max(ext[2], 1e-3);
+        h = std::cbrt(1.5 * vol / (double)std::max<int64_t>(n_valid, 1));
+        h = std::min(std::max(h, 0.05), 1.0e6);
+    }
+    int dim[3];
+    for (;;) {
+        double cells = 1;
+        bool ok = true;
+        for (int d = 0; d < 3; ++d) {
+            double c = std::floor(ext[d] / h) + 1;
+            if (c > 2.0e9) ok = false;
+            dim[d] = ok ? (int)c : 1;
+            cells *= c;
+        }
+        if (ok && cells <= 1.0e9) break; // cell table <= 4 GB
+        SF_CHECK(cell <= 0, SF_ERR_OVERFLOW, "cell %.4g gives too many cells for this extent", (double)cell);
+        h *= 1.5;
+    }
+    GridGeom g;
+    for (int d = 0; d < 3; ++d) { g.org[d] = n_valid > 0 ? mm.mn[d] : 0.0f; g.dim[d] = dim[d]; }
+    g.inv_h = (float)(1.0 / h);
+    g.ncell = (uint32_t)((uint64_t)dim[0] * dim[1] * dim[2]);
+
+    // 3. keys -> stable radix sort -> gather
+    SF_TRY(m->keys.reserve(sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)));
+    SF_TRY(m->vals.reserve(sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)));
+    SF_TRY(m->keys2.reserve(sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)));
+    SF_TRY(m->vals2.reserve(sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)));
+    SF_TRY(m->pts4.reserve(sizeof(float4) * (size_t)std::max<int64_t>(n, 1)));
+    SF_TRY(m->inv_perm.reserve(sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)));
+    SF_TRY(m->cell_start.reserve(sizeof(uint32_t) * ((size_t)g.ncell + 2)));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_cell_keys, dim3(nblk(n)), dim3(256), 0, st, xyz, n, g, m->keys.as<uint32_t>(), m->vals.as<uint32_t>());
+        unsigned bits = 1;
+        while (bits < 32 && (1ull << bits) <= (unsigned long long)g.ncell) ++bits;
+        size_t tmp = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, m->keys.as<uint32_t>(), m->keys2.as<uint32_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(),
+                                                 (size_t)n, 0, bits, st);
+        SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs(size): %s", hipGetErrorString(e));
+        SF_TRY(sf::ensure_scratch(ctx, tmp));
+        e = rocprim::radix_sort_pairs(ctx->scratch.p, tmp, m->keys.as<uint32_t>(), m->keys2.as<uint32_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), (size_t)n,
+                                      0, bits, st);
+        SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n)), dim3(256), 0, st, xyz, m->vals2.as<uint32_t>(), n, m->pts4.as<float4>(), m->inv_perm.as<uint32_t>());
+    }
+    if (n_valid > 0)
+        hipLaunchKernelGGL(k_cell_bounds, dim3(nblk(n_valid)), dim3(256), 0, st, m->keys2.as<uint32_t>(), n_valid, g.ncell, m->cell_start.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_fill_u32, dim3(nblk((int64_t)g.ncell + 1)), dim3(256), 0, st, m->cell_start.as<uint32_t>(), (int64_t)g.ncell + 1, 0u);
+    SF_HIP(hipGetLastError());
+    SF_HIP(hipStreamSynchronize(st));
+
+    m->n = n;
+    SfGrid &G = m->grid;
+    for (int d = 0; d < 3; ++d) { G.org[d] = g.org[d]; G.dim[d] = dim[d]; }
+    G.inv_h = g.inv_h;
+    G.h = (float)h;
+    G.cell_start = m->cell_start.as<uint32_t>();
+    G.pts = m->pts4.as<float4>();
+    G.nrm = nullptr;
+    G.n = n_valid;
+    m->built = true;
+    return SF_OK;
+}
+
+extern "C" int sf_map_size(sf_map *m, int64_t *n)
+{
+    SF_CHECK(m && n, SF_ERR_INVALID, "bad arguments");
+    *n = m->n;
+    return SF_OK;
+}
+
+extern "C" int sf_map_cell_size(sf_map *m, float *cell, int32_t dims[3])
+{
+    SF_CHECK(m && m->built, SF_ERR_STATE, "map not built");
+    if (cell) *cell = m->grid.h;
+    if (dims) for (int d = 0; d < 3; ++d) dims[d] = m->grid.dim[d];
+    return SF_OK;
+}
+
+extern "C" int sf_map_window_none(sf_map *m)
+{
+    SF_CHECK(m, SF_ERR_INVALID, "bad arguments");
+    m->window.kind = 0;
+    return SF_OK;
+}
+
+extern "C" int sf_map_window_sphere(sf_map *m, const float center[3], double radius)
+{
+    SF_CHECK(m && center, SF_ERR_INVALID, "bad arguments");
+    m->window.kind = 1;
+    for (int d = 0; d < 3; ++d) m->window.c[d] = center[d];
+    m->window.r2 = (float)(radius * radius);
+    return SF_OK;
+}
+
+extern "C" int sf_map_window_obb(sf_map *m, const double center[3], const double R[9], const double extent[3])
+{
+    SF_CHECK(m && center && R && extent, SF_ERR_INVALID, "bad arguments");
+    m->window.kind = 2;
+    for (int d = 0; d < 3; ++d) { m->window.oc[d] = center[d]; m->window.ohalf[d] = extent[d] / 2; }
+    for (int k = 0; k < 9; ++k) m->window.oR[k] = R[k];
+    return SF_OK;
+}
+
+extern "C" int sf_map_nn(sf_map *m, const float *queries, int64_t n, float max_d2, int32_t *idx, float *d2)
+{
+    SF_CHECK(m && m->built, SF_ERR_STATE, "map not built");
+    SF_CHECK(n >= 0 && (n == 0 || (queries && idx && d2)), SF_ERR_INVALID, "bad arguments");
+    if (n == 0) return SF_OK;
+    sf_ctx *ctx = m->ctx;
+    SF_HIP(hipSetDevice(ctx->device));
+    sf::DevBuf dq, di, dd;
+    SF_TRY(dq.reserve(sizeof(float) * 3 * (size_t)n));
+    SF_TRY(di.reserve(sizeof(int32_t) * (size_t)n));
+    SF_TRY(dd.reserve(sizeof(float) * (size_t)n));
+    SF_HIP(hipMemcpyAsync(dq.p, queries, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    if (m->window.kind)
+        hipLaunchKernelGGL(k_map_nn_t<true>, dim3(nblk(n)), dim3(256), 0, ctx->stream, m->grid, m->window, dq.as<float>(), n, max_d2, di.as<int32_t>(), dd.as<float>());
+    else
+        hipLaunchKernelGGL(k_map_nn_t<false>, dim3(nblk(n)), dim3(256), 0, ctx->stream, m->grid, m->window, dq.as<float>(), n, max_d2, di.as<int32_t>(), dd.as<float>());
+    SF_HIP(hipGetLastError());
+    SF_HIP(hipMemcpyAsync(idx, di.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipMemcpyAsync(d2, dd.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    dq.release(); di.release(); dd.release();
+    return SF_OK;
+}
+
+// ------------------------------------------------------------------ normals (extension x2, no reference code)
+// PCA of all neighbours within `radius` (self included), float64, two passes (mean, then
+// centred covariance); smallest-eigenvalue vector by cyclic Jacobi.  The batch is
+// 3 x k . k x 3 with k ~ 10-30: VALU work, not a dense contraction worth MFMA.
+namespace {
+
+__device__ void smallest_eigvec(const double C[9], double nrm[3])
+{
+    double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; ++i) a[i] = C[i];
+    for (int sweep = 0; sweep < 50; ++sweep) {
+        const double off = fabs(a[1]) + fabs(a[2]) + fabs(a[5]);
+        const double dia = fabs(a[0]) + fabs(a[4]) + fabs(a[8]);
+        if (off <= 1e-300 || off <= 2.220446049250313e-16 * dia * 1e-3) break;
+        for (int k = 0; k < 3; ++k) {
+            const int p = k == 2 ? 1 : 0, q = k == 0 ? 1 : 2;
+            const double apq = a[3 * p + q];
+            if (fabs(apq) < 1e-300) continue;
+            const double theta = (a[3 * q + q] - a[3 * p + p]) / (2 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+            const double c = 1 / sqrt(t * t + 1), s = t * c;
+            for (int i = 0; i < 3; ++i) {
+                const double aip = a[3 * i + p], aiq = a[3 * i + q];
+                a[3 * i + p] = c * aip - s * aiq;
+                a[3 * i + q] = s * aip + c * aiq;
+            }
+            for (int i = 0; i < 3; ++i) {
+                const double api = a[3 * p + i], aqi = a[3 * q + i];
+                a[3 * p + i] = c * api - s * aqi;
+                a[3 * q + i] = s * api + c * aqi;
+            }
+            for (int i = 0; i < 3; ++i) {
+                const double vip = v[3 * i + p], viq = v[3 * i + q];
+                v[3 * i + p] = c * vip - s * viq;
+                v[3 * i + q] = s * vip + c * viq;
+            }
+        }
+    }
+    int best = 0;
+    if (a[4] < a[3 * best + best]) best = 1;
+    if (a[8] < a[3 * best + best]) best = 2;
+    double x = v[best], y = v[3 + best], z = v[6 + best];
+    const double nn = sqrt(x * x + y * y + z * z);
+    if (!(nn > 0)) { nrm[0] = 0; nrm[1] = 0; nrm[2] = 1; return; }
+    x /= nn; y /= nn; z /= nn;
+    if (z < 0 || (z == 0 && (y < 0 || (y == 0 && x < 0)))) { x = -x; y = -y; z = -z; }
+    nrm[0] = x; nrm[1] = y; nrm[2] = z;
+}
+
+__global__ __launch_bounds__(256) void k_normals(SfGrid g, double r2, int R, float4 *__restrict__ nrm4)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= g.n) return;
+    const float4 p = g.pts[j];
+    const int nx = g.dim[0], ny = g.dim[1], nz = g.dim[2];
+    const int cx = (int)fminf(fmaxf(floorf((p.x - g.org[0]) * g.inv_h), 0.0f), (float)(nx - 1));
+    const int cy = (int)fminf(fmaxf(floorf((p.y - g.org[1]) * g.inv_h), 0.0f), (float)(ny - 1));
+    const int cz = (int)fminf(fmaxf(floorf((p.z - g.org[2]) * g.inv_h), 0.0f), (float)(nz - 1));
+    const int x0 = max(cx - R, 0), x1 = min(cx + R, nx - 1);
+    const int y0 = max(cy - R, 0), y1 = min(cy + R, ny - 1);
+    const int z0 = max(cz - R, 0), z1 = min(cz + R, nz - 1);
+    double sum[3] = {0, 0, 0}, mean[3] = {0, 0, 0}, C[6] = {0, 0, 0, 0, 0, 0};
+    int cnt = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            if (cnt < 3) break;
+            for (int d = 0; d < 3; ++d) mean[d] = sum[d] / cnt;
+        }
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const size_t row = ((size_t)z * ny + y) * nx;
+                const uint32_t a = g.cell_start[row + x0], b = g.cell_start[row + x1 + 1];
+                for (uint32_t k = a; k < b; ++k) {
+                    const float4 q = g.pts[k];
+                    const double ex = (double)q.x - (double)p.x, ey = (double)q.y - (double)p.y, ez = (double)q.z - (double)p.z;
+                    if (!(ex * ex + ey * ey + ez * ez <= r2)) continue;
+                    if (pass == 0) { sum[0] += q.x; sum[1] += q.y; sum[2] += q.z; ++cnt; }
+                    else {
+                        const double ax = q.x - mean[0], ay = q.y - mean[1], az = q.z - mean[2];
+                        C[0] += ax * ax; C[1] += ax * ay; C[2] += ax * az; C[3] += ay * ay; C[4] += ay * az; C[5] += az * az;
+                    }
+                }
+            }
+    }
+    double nv[3] = {0, 0, 1};
+    if (cnt >= 3) {
+        const double M[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
+        smallest_eigvec(M, nv);
+    }
+    nrm4[j] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], __int_as_float(cnt));
+}
+
+__global__ void k_normals_from_host_order(SfGrid g, const float *__restrict__ nrm_orig, float4 *__restrict__ nrm4)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= g.n) return;
+    const uint32_t i = __float_as_uint(g.pts[j].w);
+    nrm4[j] = make_float4(nrm_orig[3 * (size_t)i], nrm_orig[3 * (size_t)i + 1], nrm_orig[3 * (size_t)i + 2], __int_as_float(0));
+}
+
+__global__ void k_normals_to_host_order(SfGrid g, const float4 *__restrict__ nrm4, float *__restrict__ nrm_orig, int32_t *__restrict__ cnt_orig)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= g.n) return;
+    const uint32_t i = __float_as_uint(g.pts[j].w);
+    const float4 v = nrm4[j];
+    nrm_orig[3 * (size_t)i] = v.x; nrm_orig[3 * (size_t)i + 1] = v.y; nrm_orig[3 * (size_t)i + 2] = v.z;
+    cnt_orig[i] = __float_as_int(v.w);
+}
+
+} // namespace
+
+extern "C" int sf_map_estimate_normals(sf_map *m, float radius)
+{
+    SF_CHECK(m && m->built, SF_ERR_STATE, "map not built");
+    SF_CHECK(radius > 0, SF_ERR_INVALID, "radius must be positive");
+    sf_ctx *ctx = m->ctx;
+    SF_HIP(hipSetDevice(ctx->device));
+    SF_TRY(m->nrm4.reserve(sizeof(float4) * (size_t)std::max<int64_t>(m->n, 1)));
+    const int R = std::max(1, (int)std::ceil((double)radius / (double)m->grid.h - 1e-9));
+    if (m->grid.n > 0)
+        hipLaunchKernelGGL(k_normals, dim3(nblk(m->grid.n)), dim3(256), 0, ctx->stream, m->grid, (double)radius * (double)radius, R, m->nrm4.as<float4>());
+    SF_HIP(hipGetLastError());
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    m->grid.nrm = m->nrm4.as<float4>();
+    m->has_normals = true;
+    return SF_OK;
+}
+
+extern "C" int sf_map_set_normals(sf_map *m, const float *normals, int64_t n)
+{
+    SF_CHECK(m && m->built, SF_ERR_STATE, "map not built");
+    SF_CHECK(normals && n == m->n, SF_ERR_INVALID, "normals must match the map size (%lld)", (long long)m->n);
+    sf_ctx *ctx = m->ctx;
+    SF_HIP(hipSetDevice(ctx->device));
+    SF_TRY(m->nrm4.reserve(sizeof(float4) * (size_t)std::max<int64_t>(m->n, 1)));
+    sf::DevBuf tmp;
+    SF_TRY(tmp.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(n, 1)));
+    SF_HIP(hipMemcpyAsync(tmp.p, normals, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    if (m->grid.n > 0)
+        hipLaunchKernelGGL(k_normals_from_host_order, dim3(nblk(m->grid.n)), dim3(256), 0, ctx->stream, m->grid, tmp.as<float>(), m->nrm4.as<float4>());
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    tmp.release();
+    m->grid.nrm = m->nrm4.as<float4>();
+    m->has_normals = true;
+    return SF_OK;
+}
+
+extern "C" int sf_map_download_normals(sf_map *m, float *normals, int32_t *n_neighbors, int64_t cap, int64_t *n)
+{
+    SF_CHECK(m && m->built && m->has_normals, SF_ERR_STATE, "no normals");
+    if (n) *n = m->n;
+    SF_CHECK(cap >= m->n && normals, SF_ERR_INVALID, "buffer too small");
+    sf_ctx *ctx = m->ctx;
+    SF_HIP(hipSetDevice(ctx->device));
+    sf::DevBuf dn, dc;
+    SF_TRY(dn.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(m->n, 1)));
+    SF_TRY(dc.reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(m->n, 1)));
+    SF_HIP(hipMemsetAsync(dn.p, 0, sizeof(float) * 3 * (size_t)std::max<int64_t>(m->n, 1), ctx->stream));
+    SF_HIP(hipMemsetAsync(dc.p, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(m->n, 1), ctx->stream));
+    if (m->grid.n > 0)
+        hipLaunchKernelGGL(k_normals_to_host_order, dim3(nblk(m->grid.n)), dim3(256), 0, ctx->stream, m->grid, m->nrm4.as<float4>(), dn.as<float>(), dc.as<int32_t>());
+    SF_HIP(hipMemcpyAsync(normals, dn.p, sizeof(float) * 3 * (size_t)m->n, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_neighbors) SF_HIP(hipMemcpyAsync(n_neighbors, dc.p, sizeof(int32_t) * (size_t)m->n, hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    dn.release(); dc.release();
+    return SF_OK;
+}

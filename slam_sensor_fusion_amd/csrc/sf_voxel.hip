@@ -1,0 +1,304 @@
+// sf_voxel.hip — voxel-grid downsampling of the map on the device (gfx950).
+//
+// SF_VOXEL_PCL restates pcl::VoxelGrid<PointXYZ> (float32) as the reference calls it at
+// localization/src/global_map_frames_manager.cpp:142-146 (leaf 0.1f from
+// localization/src/localization_node.cpp:19): int32 linear voxel index
+// i + j*dx + k*dx*dy of floor(p * (1/leaf)) - min_b, centroid per voxel, output in
+// ascending index order; int32 overflow -> input returned unchanged (PCL warns).
+// SF_VOXEL_O3D restates Open3D voxel_down_sample (float64) as called at
+// localization_python/localization_python/localization_node.py:47: index
+// floor((p - (min_bound - v/2)) / v), float64 mean per voxel.
+// Pipeline: key kernel -> stable rocPRIM radix sort of (key, point id) -> head flags ->
+// exclusive scan -> one lane per voxel sums its points sequentially in ascending point
+// id (so the float32 / float64 sums are bit-identical to the oracle's) -> scatter.
+#include "sf_common.hpp"
+
+#include <rocprim/rocprim.hpp>
+#include <climits>
+#include <cmath>
+
+namespace {
+
+inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)sf::div_up(n > 0 ? n : 1, b); }
+
+struct PclGeom { float inv; int min_b[3]; int mul[3]; };
+
+__global__ void k_pcl_keys(const float *__restrict__ xyz, int64_t n, PclGeom g, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, int32_t *__restrict__ point_ids)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    uint32_t key = 0xffffffffu;
+    int32_t id = -1;
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+        // voxel_grid.hpp: static_cast<int>(std::floor(p.x * inverse_leaf_size_[0]) - static_cast<float>(min_b_[0]))
+        const int i0 = (int)(floorf(__fmul_rn(x, g.inv)) - (float)g.min_b[0]);
+        const int i1 = (int)(floorf(__fmul_rn(y, g.inv)) - (float)g.min_b[1]);
+        const int i2 = (int)(floorf(__fmul_rn(z, g.inv)) - (float)g.min_b[2]);
+        id = i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2];
+        key = (uint32_t)id;
+    }
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
+    point_ids[i] = id;
+}
+
+struct O3dGeom { double vmin[3]; double voxel; };
+
+__global__ void k_o3d_keys(const float *__restrict__ xyz, int64_t n, O3dGeom g, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, int32_t *__restrict__ point_ijk)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // ref_coord = (p - voxel_min_bound) / voxel_size, float64 (PointCloud.cpp VoxelDownSample)
+    const int a = (int)floor(__ddiv_rn((double)xyz[3 * i] - g.vmin[0], g.voxel));
+    const int b = (int)floor(__ddiv_rn((double)xyz[3 * i + 1] - g.vmin[1], g.voxel));
+    const int c = (int)floor(__ddiv_rn((double)xyz[3 * i + 2] - g.vmin[2], g.voxel));
+    keys[i] = ((uint64_t)(uint32_t)a << 42) | ((uint64_t)(uint32_t)b << 21) | (uint64_t)(uint32_t)c;
+    vals[i] = (uint32_t)i;
+    point_ijk[3 * i] = a; point_ijk[3 * i + 1] = b; point_ijk[3 * i + 2] = c;
+}
+
+template <class K>
+__global__ void k_heads(const K *__restrict__ keys, int64_t n_valid, uint32_t *__restrict__ flags)
+{
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_valid) return;
+    flags[j] = (j == 0 || keys[j] != keys[j - 1]) ? 1u : 0u;
+}
+
+// one lane per voxel: float32 sums in ascending point id (pcl::CentroidPoint / AccumulatorXYZ)
+__global__ void k_pcl_centroids(const float *__restrict__ xyz, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ flags,
+                                const uint32_t *__restrict__ pos, int64_t n_valid, float *__restrict__ out, int32_t *__restrict__ out_ids)
+{
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_valid || !flags[j]) return;
+    const uint32_t key = keys[j];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    int cnt = 0;
+    for (int64_t k = j; k < n_valid && keys[k] == key; ++k) {
+        const size_t p = vals[k];
+        sx = __fadd_rn(sx, xyz[3 * p]);
+        sy = __fadd_rn(sy, xyz[3 * p + 1]);
+        sz = __fadd_rn(sz, xyz[3 * p + 2]);
+        ++cnt;
+    }
+    const float c = (float)cnt;
+    const size_t o = pos[j];
+    out[3 * o] = __fdiv_rn(sx, c); out[3 * o + 1] = __fdiv_rn(sy, c); out[3 * o + 2] = __fdiv_rn(sz, c);
+    out_ids[o] = (int32_t)key;
+}
+
+// float64 means in ascending point id (open3d AccumulatedPoint)
+__global__ void k_o3d_means(const float *__restrict__ xyz, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ flags,
+                            const uint32_t *__restrict__ pos, int64_t n, float *__restrict__ out, double *__restrict__ out64, int32_t *__restrict__ out_ijk)
+{
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || !flags[j]) return;
+    const uint64_t key = keys[j];
+    double sx = 0, sy = 0, sz = 0;
+    int cnt = 0;
+    for (int64_t k = j; k < n && keys[k] == key; ++k) {
+        const size_t p = vals[k];
+        sx = __dadd_rn(sx, (double)xyz[3 * p]);
+        sy = __dadd_rn(sy, (double)xyz[3 * p + 1]);
+        sz = __dadd_rn(sz, (double)xyz[3 * p + 2]);
+        ++cnt;
+    }
+    const double c = (double)cnt;
+    const size_t o = pos[j];
+    const double mx = __ddiv_rn(sx, c), my = __ddiv_rn(sy, c), mz = __ddiv_rn(sz, c);
+    out64[3 * o] = mx; out64[3 * o + 1] = my; out64[3 * o + 2] = mz;
+    out[3 * o] = (float)mx; out[3 * o + 1] = (float)my; out[3 * o + 2] = (float)mz;
+    out_ijk[3 * o] = (int32_t)(key >> 42); out_ijk[3 * o + 1] = (int32_t)((key >> 21) & 0x1fffff); out_ijk[3 * o + 2] = (int32_t)(key & 0x1fffff);
+}
+
+// heads -> exclusive scan -> number of voxels (synchronises)
+template <class K>
+int scan_heads(sf_ctx *ctx, const K *keys, int64_t n_valid, uint32_t *flags, uint32_t *pos, int64_t *n_vox)
+{
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_heads<K>, dim3(nblk(n_valid)), dim3(256), 0, st, keys, n_valid, flags);
+    size_t tmp = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, tmp, flags, pos, 0u, (size_t)n_valid, rocprim::plus<uint32_t>(), st);
+    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "exclusive_scan(size): %s", hipGetErrorString(e));
+    SF_TRY(sf::ensure_scratch(ctx, tmp));
+    e = rocprim::exclusive_scan(ctx->scratch.p, tmp, flags, pos, 0u, (size_t)n_valid, rocprim::plus<uint32_t>(), st);
+    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "exclusive_scan: %s", hipGetErrorString(e));
+    uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
+    SF_HIP(hipMemcpyAsync(h, pos + (n_valid - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SF_HIP(hipMemcpyAsync(h + 1, flags + (n_valid - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SF_HIP(hipStreamSynchronize(st));
+    *n_vox = (int64_t)h[0] + (int64_t)h[1];
+    return SF_OK;
+}
+
+int voxel_pcl(sf_cloud *c, float leaf, int *status_flags)
+{
+    sf_ctx *ctx = c->ctx;
+    hipStream_t st = ctx->stream;
+    const int64_t n = c->n;
+    sf::MinMaxHost mm;
+    SF_TRY(sf::cloud_minmax(ctx, c->xyz.as<float>(), n, &mm));
+    if (mm.n_finite == 0) { c->n = 0; return SF_OK; }
+    const float inv = 1.0f / leaf;
+    // voxel_grid.hpp overflow test, float32 arithmetic then int64
+    const int64_t dx = (int64_t)((mm.mx[0] - mm.mn[0]) * inv) + 1;
+    const int64_t dy = (int64_t)((mm.mx[1] - mm.mn[1]) * inv) + 1;
+    const int64_t dz = (int64_t)((mm.mx[2] - mm.mn[2]) * inv) + 1;
+    if (dx * dy * dz > (int64_t)INT32_MAX) {
+        if (status_flags) *status_flags |= SF_FLAG_VOXEL_OVERFLOW;
+        return SF_OK; // "Leaf size is too small ... Integer indices would overflow": output = input
+    }
+    PclGeom g;
+    g.inv = inv;
+    int div_b[3];
+    for (int d = 0; d < 3; ++d) {
+        g.min_b[d] = (int)std::floor(mm.mn[d] * inv);
+        const int max_b = (int)std::floor(mm.mx[d] * inv);
+        div_b[d] = max_b - g.min_b[d] + 1;
+    }
+    g.mul[0] = 1; g.mul[1] = div_b[0]; g.mul[2] = div_b[0] * div_b[1];
+
+    sf::DevBuf keys, keys2, vals, vals2, flags, pos, out;
+    int rc = SF_OK;
+    auto cleanup = [&]() { keys.release(); keys2.release(); vals.release(); vals2.release(); flags.release(); pos.release(); };
+#define VX_TRY(e) do { rc = (e); if (rc != SF_OK) { cleanup(); out.release(); return rc; } } while (0)
+    VX_TRY(keys.reserve(sizeof(uint32_t) * (size_t)n));
+    VX_TRY(keys2.reserve(sizeof(uint32_t) * (size_t)n));
+    VX_TRY(vals.reserve(sizeof(uint32_t) * (size_t)n));
+    VX_TRY(vals2.reserve(sizeof(uint32_t) * (size_t)n));
+    VX_TRY(flags.reserve(sizeof(uint32_t) * (size_t)n));
+    VX_TRY(pos.reserve(sizeof(uint32_t) * (size_t)n));
+    VX_TRY(c->vox_point_ids.reserve(sizeof(int32_t) * (size_t)n));
+    hipLaunchKernelGGL(k_pcl_keys, dim3(nblk(n)), dim3(256), 0, st, c->xyz.as<float>(), n, g, keys.as<uint32_t>(), vals.as<uint32_t>(), c->vox_point_ids.as<int32_t>());
+    size_t tmp = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, keys.as<uint32_t>(), keys2.as<uint32_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), (size_t)n, 0, 32, st);
+    if (e != hipSuccess) { sf::set_error("radix_sort_pairs(size): %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
+    VX_TRY(sf::ensure_scratch(ctx, tmp));
+    e = rocprim::radix_sort_pairs(ctx->scratch.p, tmp, keys.as<uint32_t>(), keys2.as<uint32_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), (size_t)n, 0, 32, st);
+    if (e != hipSuccess) { sf::set_error("radix_sort_pairs: %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
+    int64_t n_vox = 0;
+    VX_TRY(scan_heads<uint32_t>(ctx, keys2.as<uint32_t>(), mm.n_finite, flags.as<uint32_t>(), pos.as<uint32_t>(), &n_vox));
+    VX_TRY(out.reserve(sizeof(float) * 3 * (size_t)n_vox));
+    VX_TRY(c->vox_out_ids.reserve(sizeof(int32_t) * (size_t)n_vox));
+    hipLaunchKernelGGL(k_pcl_centroids, dim3(nblk(mm.n_finite)), dim3(256), 0, st, c->xyz.as<float>(), keys2.as<uint32_t>(), vals2.as<uint32_t>(), flags.as<uint32_t>(),
+                       pos.as<uint32_t>(), mm.n_finite, out.as<float>(), c->vox_out_ids.as<int32_t>());
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { sf::set_error("voxel kernels: %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
+#undef VX_TRY
+    cleanup();
+    c->xyz.release();
+    c->xyz = out;
+    c->n_vox_point_vals = n;
+    c->n_vox_out_vals = n_vox;
+    c->n_vox_out_pts = 0;
+    c->n = n_vox;
+    c->n_last_idx = -1;
+    return SF_OK;
+}
+
+int voxel_o3d(sf_cloud *c, double voxel)
+{
+    sf_ctx *ctx = c->ctx;
+    hipStream_t st = ctx->stream;
+    const int64_t n = c->n;
+    sf::MinMaxHost mm;
+    SF_TRY(sf::cloud_minmax(ctx, c->xyz.as<float>(), n, &mm));
+    SF_CHECK(mm.n_finite == n, SF_ERR_INVALID, "Open3D-flavour voxel grid needs finite points (%lld of %lld are)", (long long)mm.n_finite, (long long)n);
+    O3dGeom g;
+    g.voxel = voxel;
+    double span = 0;
+    for (int d = 0; d < 3; ++d) {
+        g.vmin[d] = (double)mm.mn[d] - voxel * 0.5;
+        const double vmax = (double)mm.mx[d] + voxel * 0.5;
+        span = std::max(span, vmax - g.vmin[d]);
+    }
+    SF_CHECK(!(voxel * (double)INT_MAX < span), SF_ERR_OVERFLOW, "voxel_size is too small.");
+    SF_CHECK(span / voxel + 2 < 2097152.0, SF_ERR_OVERFLOW, "more than 2^21 voxels along one axis");
+
+    sf::DevBuf keys, keys2, vals, vals2, flags, pos, out;
+    int rc = SF_OK;
+    auto cleanup = [&]() { keys.release(); keys2.release(); vals.release(); vals2.release(); flags.release(); pos.release(); };
+#define VX_TRY(e) do { rc = (e); if (rc != SF_OK) { cleanup(); out.release(); return rc; } } while (0)
+    VX_TRY(keys.reserve(sizeof(uint64_t) * (size_t)n));
+    VX_TRY(keys2.reserve(sizeof(uint64_t) * (size_t)n));
+    VX_TRY(vals.reserve(sizeof(uint32_t) * (size_t)n));
+    VX_TRY(vals2.reserve(sizeof(uint32_t) * (size_t)n));
+    VX_TRY(flags.reserve(sizeof(uint32_t) * (size_t)n));
+    VX_TRY(pos.reserve(sizeof(uint32_t) * (size_t)n));
+    VX_TRY(c->vox_point_ids.reserve(sizeof(int32_t) * 3 * (size_t)n));
+    hipLaunchKernelGGL(k_o3d_keys, dim3(nblk(n)), dim3(256), 0, st, c->xyz.as<float>(), n, g, keys.as<uint64_t>(), vals.as<uint32_t>(), c->vox_point_ids.as<int32_t>());
+    size_t tmp = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), (size_t)n, 0, 63, st);
+    if (e != hipSuccess) { sf::set_error("radix_sort_pairs(size): %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
+    VX_TRY(sf::ensure_scratch(ctx, tmp));
+    e = rocprim::radix_sort_pairs(ctx->scratch.p, tmp, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), (size_t)n, 0, 63, st);
+    if (e != hipSuccess) { sf::set_error("radix_sort_pairs: %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
+    int64_t n_vox = 0;
+    VX_TRY(scan_heads<uint64_t>(ctx, keys2.as<uint64_t>(), n, flags.as<uint32_t>(), pos.as<uint32_t>(), &n_vox));
+    VX_TRY(out.reserve(sizeof(float) * 3 * (size_t)n_vox));
+    VX_TRY(c->vox_out_ids.reserve(sizeof(int32_t) * 3 * (size_t)n_vox));
+    VX_TRY(c->vox_out_means.reserve(sizeof(double) * 3 * (size_t)n_vox));
+    hipLaunchKernelGGL(k_o3d_means, dim3(nblk(n)), dim3(256), 0, st, c->xyz.as<float>(), keys2.as<uint64_t>(), vals2.as<uint32_t>(), flags.as<uint32_t>(), pos.as<uint32_t>(), n,
+                       out.as<float>(), c->vox_out_means.as<double>(), c->vox_out_ids.as<int32_t>());
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { sf::set_error("voxel kernels: %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
+#undef VX_TRY
+    cleanup();
+    c->xyz.release();
+    c->xyz = out;
+    c->n_vox_point_vals = 3 * n;
+    c->n_vox_out_vals = 3 * n_vox;
+    c->n_vox_out_pts = n_vox;
+    c->n = n_vox;
+    c->n_last_idx = -1;
+    return SF_OK;
+}
+
+int download_i32(sf_cloud *c, const sf::DevBuf &buf, int64_t have, int32_t *dst, int64_t cap, int64_t *n)
+{
+    if (n) *n = have;
+    SF_CHECK(cap >= have && (dst || have == 0), SF_ERR_INVALID, "buffer too small: %lld < %lld", (long long)cap, (long long)have);
+    if (have > 0) {
+        SF_HIP(hipMemcpyAsync(dst, buf.p, sizeof(int32_t) * (size_t)have, hipMemcpyDeviceToHost, c->ctx->stream));
+        SF_HIP(hipStreamSynchronize(c->ctx->stream));
+    }
+    return SF_OK;
+}
+
+} // namespace
+
+extern "C" int sf_cloud_voxel_downsample(sf_cloud *c, double leaf, int flavour, int *status_flags)
+{
+    SF_CHECK(c && leaf > 0, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(flavour == SF_VOXEL_PCL || flavour == SF_VOXEL_O3D, SF_ERR_INVALID, "unknown voxel flavour %d", flavour);
+    SF_HIP(hipSetDevice(c->ctx->device));
+    if (status_flags) *status_flags = 0;
+    c->n_vox_point_vals = c->n_vox_out_vals = c->n_vox_out_pts = 0;
+    if (c->n == 0) return SF_OK;
+    return flavour == SF_VOXEL_PCL ? voxel_pcl(c, (float)leaf, status_flags) : voxel_o3d(c, leaf);
+}
+
+extern "C" int sf_cloud_voxel_point_ids(sf_cloud *c, int32_t *ids, int64_t cap_values, int64_t *n_values)
+{
+    SF_CHECK(c, SF_ERR_INVALID, "bad arguments");
+    return download_i32(c, c->vox_point_ids, c->n_vox_point_vals, ids, cap_values, n_values);
+}
+
+extern "C" int sf_cloud_voxel_out_ids(sf_cloud *c, int32_t *ids, int64_t cap_values, int64_t *n_values)
+{
+    SF_CHECK(c, SF_ERR_INVALID, "bad arguments");
+    return download_i32(c, c->vox_out_ids, c->n_vox_out_vals, ids, cap_values, n_values);
+}
+
+extern "C" int sf_cloud_voxel_out_means_f64(sf_cloud *c, double *xyz, int64_t cap_points, int64_t *n_points)
+{
+    SF_CHECK(c, SF_ERR_INVALID, "bad arguments");
+    if (n_points) *n_points = c->n_vox_out_pts;
+    SF_CHECK(cap_points >= c->n_vox_out_pts && (xyz || c->n_vox_out_pts == 0), SF_ERR_INVALID, "buffer too small");
+    if (c->n_vox_out_pts > 0) {
+        SF_HIP(hipMemcpyAsync(xyz, c->vox_out_means.p, sizeof(double) * 3 * (size_t)c->n_vox_out_pts, hipMemcpyDeviceToHost, c->ctx->stream));
+        SF_HIP(hipStreamSynchronize(c->ctx->stream));
+    }
+    return SF_OK;
+}
