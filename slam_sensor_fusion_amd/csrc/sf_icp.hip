@@ -51,66 +51,89 @@ struct IcpParams {
 inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)sf::div_up(n > 0 ? n : 1, b); }
 
 // ------------------------------------------------------------------ small device linear algebra (one lane)
-__device__ void mat4_mul(const double A[16], const double B[16], double C[16])
+// Every loop below has compile-time bounds and is fully unrolled so the little matrices
+// live in registers (runtime-indexed arrays would go to scratch memory).
+__device__ __forceinline__ void mat4_mul(const double A[16], const double B[16], double C[16])
 {
     double R[16];
+#pragma unroll
     for (int r = 0; r < 4; ++r)
+#pragma unroll
         for (int c = 0; c < 4; ++c)
             R[4 * r + c] = A[4 * r] * B[c] + A[4 * r + 1] * B[4 + c] + A[4 * r + 2] * B[8 + c] + A[4 * r + 3] * B[12 + c];
+#pragma unroll
     for (int i = 0; i < 16; ++i) C[i] = R[i];
+}
+
+template <int P, int Q>
+__device__ __forceinline__ bool jacobi_pair(double (&u)[9], double (&v)[9])
+{
+    double al = 0, be = 0, ga = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        al += u[3 * i + P] * u[3 * i + P];
+        be += u[3 * i + Q] * u[3 * i + Q];
+        ga += u[3 * i + P] * u[3 * i + Q];
+    }
+    if (fabs(ga) <= DBL_EPSILON * sqrt(al * be) || fabs(ga) < 1e-300) return false;
+    const double zeta = (be - al) / (2 * ga);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+    const double c = 1 / sqrt(1 + t * t), s = c * t;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double a = u[3 * i + P], b = u[3 * i + Q];
+        u[3 * i + P] = c * a - s * b;
+        u[3 * i + Q] = s * a + c * b;
+        a = v[3 * i + P]; b = v[3 * i + Q];
+        v[3 * i + P] = c * a - s * b;
+        v[3 * i + Q] = s * a + c * b;
+    }
+    return true;
+}
+
+template <int A, int B>
+__device__ __forceinline__ void swap_cols_if_less(double (&s)[3], double (&u)[9], double (&v)[9])
+{
+    if (s[B] > s[A]) {
+        double t = s[A]; s[A] = s[B]; s[B] = t;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            t = u[3 * i + A]; u[3 * i + A] = u[3 * i + B]; u[3 * i + B] = t;
+            t = v[3 * i + A]; v[3 * i + A] = v[3 * i + B]; v[3 * i + B] = t;
+        }
+    }
 }
 
 // one-sided Jacobi SVD of a 3x3 (row-major), S descending — stands in for
 // Eigen::JacobiSVD<Matrix3f> at icp_point_to_point.cpp:137 (float64 here)
-__device__ void svd3(const double A[9], double U[9], double S[3], double V[9])
+__device__ __forceinline__ void svd3(const double (&A)[9], double (&U)[9], double (&S)[3], double (&V)[9])
 {
-    double u[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    for (int i = 0; i < 9; ++i) u[i] = A[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { U[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
     for (int sweep = 0; sweep < 60; ++sweep) {
-        int rotated = 0;
-        for (int k = 0; k < 3; ++k) {
-            const int p = k == 2 ? 1 : 0, q = k == 0 ? 1 : 2;
-            double al = 0, be = 0, ga = 0;
-            for (int i = 0; i < 3; ++i) {
-                al += u[3 * i + p] * u[3 * i + p];
-                be += u[3 * i + q] * u[3 * i + q];
-                ga += u[3 * i + p] * u[3 * i + q];
-            }
-            if (fabs(ga) <= DBL_EPSILON * sqrt(al * be) || fabs(ga) < 1e-300) continue;
-            const double zeta = (be - al) / (2 * ga);
-            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-            const double c = 1 / sqrt(1 + t * t), s = c * t;
-            for (int i = 0; i < 3; ++i) {
-                double a = u[3 * i + p], b = u[3 * i + q];
-                u[3 * i + p] = c * a - s * b;
-                u[3 * i + q] = s * a + c * b;
-                a = v[3 * i + p]; b = v[3 * i + q];
-                v[3 * i + p] = c * a - s * b;
-                v[3 * i + q] = s * a + c * b;
-            }
-            rotated = 1;
-        }
+        bool rotated = jacobi_pair<0, 1>(U, V);
+        rotated = jacobi_pair<0, 2>(U, V) || rotated;
+        rotated = jacobi_pair<1, 2>(U, V) || rotated;
         if (!rotated) break;
     }
-    double s[3];
-    int ord[3] = {0, 1, 2};
-    for (int j = 0; j < 3; ++j) s[j] = sqrt(u[j] * u[j] + u[3 + j] * u[3 + j] + u[6 + j] * u[6 + j]);
-    for (int a = 0; a < 2; ++a)
-        for (int b = a + 1; b < 3; ++b)
-            if (s[ord[b]] > s[ord[a]]) { int tmp = ord[a]; ord[a] = ord[b]; ord[b] = tmp; }
-    for (int j = 0; j < 3; ++j) {
-        const int o = ord[j];
-        S[j] = s[o];
-        for (int i = 0; i < 3; ++i) { U[3 * i + j] = u[3 * i + o]; V[3 * i + j] = v[3 * i + o]; }
-    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) S[j] = sqrt(U[j] * U[j] + U[3 + j] * U[3 + j] + U[6 + j] * U[6 + j]);
+    swap_cols_if_less<0, 1>(S, U, V);
+    swap_cols_if_less<0, 2>(S, U, V);
+    swap_cols_if_less<1, 2>(S, U, V);
     const double thr = S[0] * DBL_EPSILON * 8;
     int rank = 0;
+#pragma unroll
     for (int j = 0; j < 3; ++j)
         if (S[j] > thr && S[j] > 0) {
+#pragma unroll
             for (int i = 0; i < 3; ++i) U[3 * i + j] /= S[j];
             ++rank;
         }
-    if (rank == 0) { for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    if (rank == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
     if (rank == 1) {
         const double a0 = U[0], a1 = U[3], a2 = U[6];
         double b0, b1, b2;
@@ -130,68 +153,106 @@ __device__ void svd3(const double A[9], double U[9], double S[3], double V[9])
 
 // Kabsch step (icp_point_to_point.cpp:112-159) from the uncentred sums of the record:
 // rec[0]=n, [1..3]=sum s, [4..6]=sum t, [7..15]=sum s t^T.  H = sum s t^T - n cs ct^T.
-__device__ void kabsch_from_record(const double *rec, double T[16])
+__device__ __forceinline__ void kabsch_from_record(const double *rec, double (&T)[16])
 {
     const double n = rec[0];
     double cs[3], ct[3], H[9];
+#pragma unroll
     for (int d = 0; d < 3; ++d) { cs[d] = rec[1 + d] / n; ct[d] = rec[4 + d] / n; }
+#pragma unroll
     for (int r = 0; r < 3; ++r)
+#pragma unroll
         for (int c = 0; c < 3; ++c) H[3 * r + c] = rec[7 + 3 * r + c] - n * cs[r] * ct[c];
     double U[9], S[3], V[9], R[9];
     svd3(H, U, S, V);
+#pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
         for (int r = 0; r < 3; ++r)
+#pragma unroll
             for (int c = 0; c < 3; ++c)
                 R[3 * r + c] = V[3 * r] * U[3 * c] + V[3 * r + 1] * U[3 * c + 1] + V[3 * r + 2] * U[3 * c + 2];
         const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
         if (pass == 1 || !(det < 0)) break;
         V[2] = -V[2]; V[5] = -V[5]; V[8] = -V[8];
     }
+#pragma unroll
     for (int i = 0; i < 16; ++i) T[i] = 0;
     T[15] = 1;
+#pragma unroll
     for (int r = 0; r < 3; ++r) {
+#pragma unroll
         for (int c = 0; c < 3; ++c) T[4 * r + c] = R[3 * r + c];
         T[4 * r + 3] = ct[r] - (R[3 * r] * cs[0] + R[3 * r + 1] * cs[1] + R[3 * r + 2] * cs[2]);
     }
 }
 
-__device__ int ldlt6(const double A[36], const double b[6], double x[6])
+__device__ __forceinline__ int ldlt6(const double (&A)[36], const double (&b)[6], double (&x)[6])
 {
     double L[36], D[6], y[6];
+    bool bad = false;
+#pragma unroll
     for (int i = 0; i < 36; ++i) L[i] = 0;
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = A[6 * j + j];
+#pragma unroll
         for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k] * D[k];
-        if (!(fabs(d) > 0) || !isfinite(d)) return -1;
+        if (!(fabs(d) > 0) || !isfinite(d)) bad = true;
         D[j] = d;
         L[6 * j + j] = 1;
+#pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double v = A[6 * i + j];
+#pragma unroll
             for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k] * D[k];
             L[6 * i + j] = v / d;
         }
     }
-    for (int i = 0; i < 6; ++i) { double v = b[i]; for (int k = 0; k < i; ++k) v -= L[6 * i + k] * y[k]; y[i] = v; }
+    if (bad) return -1;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v -= L[6 * i + k] * y[k];
+        y[i] = v;
+    }
+#pragma unroll
     for (int i = 0; i < 6; ++i) y[i] /= D[i];
-    for (int i = 5; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * x[k]; x[i] = v; }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double v = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * x[k];
+        x[i] = v;
+    }
     return 0;
 }
 
 // R = Rz(v2) Ry(v1) Rx(v0), t = v[3:6] (Open3D TransformVector6dToMatrix4d)
-__device__ void vec6_to_mat4(const double v[6], double T[16])
+__device__ __forceinline__ void vec6_to_mat4(const double (&v)[6], double (&T)[16])
 {
     const double ca = cos(v[0]), sa = sin(v[0]), cb = cos(v[1]), sb = sin(v[1]), cg = cos(v[2]), sg = sin(v[2]);
     const double R[9] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa,
                          sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa,
                          -sb, cb * sa, cb * ca};
+#pragma unroll
     for (int i = 0; i < 16; ++i) T[i] = 0;
     T[15] = 1;
-    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T[4 * r + c] = R[3 * r + c]; T[4 * r + 3] = v[3 + r]; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) T[4 * r + c] = R[3 * r + c];
+        T[4 * r + 3] = v[3 + r];
+    }
 }
 
 // ------------------------------------------------------------------ reductions
+// Slab layout: partials[(scan * nblocks + block) * 32 + component] — a workgroup's record
+// is one contiguous 256-byte row, so both the store here and the column sums below are
+// coalesced.
 template <int NREC>
-__device__ __forceinline__ void block_reduce_store(double (&acc)[NREC], double *__restrict__ dst, int nblocks)
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NREC], double *__restrict__ dst)
 {
 #pragma unroll
     for (int c = 0; c < NREC; ++c) {
@@ -207,21 +268,36 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NREC], double *
     __syncthreads();
     if (threadIdx.x < NREC) {
         const int c = threadIdx.x;
-        dst[(size_t)c * nblocks] = ((s[0][c] + s[1][c]) + s[2][c]) + s[3][c];
+        dst[c] = ((s[0][c] + s[1][c]) + s[2][c]) + s[3][c];
     }
 }
 
-// sums the slab of one scan in a fixed order into rec[] (shared); all 256 threads take part
+// Fixed-order sum of one scan's slab by RBLK = 1024 threads: thread (slice s, component c)
+// adds rows s, s+32, s+64, ... then the 32 slices are added in order.  Result in rec[]
+// (shared).  Deterministic: no atomics, the order depends only on nblocks.
+constexpr int RBLK = 1024;
 template <int NREC>
 __device__ __forceinline__ void reduce_partials(const double *__restrict__ part, int nblocks, double *rec)
 {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int c = w; c < NREC; c += BLK / 64) {
+    __shared__ double sl[32][REC_STRIDE + 1];
+    const int c = threadIdx.x & 31, sidx = threadIdx.x >> 5;
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    if (c < NREC) {
+        int b = sidx;
+        for (; b + 96 < nblocks; b += 128) {
+            const double a0 = part[(size_t)b * REC_STRIDE + c], a1 = part[(size_t)(b + 32) * REC_STRIDE + c];
+            const double a2 = part[(size_t)(b + 64) * REC_STRIDE + c], a3 = part[(size_t)(b + 96) * REC_STRIDE + c];
+            v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+        }
+        for (; b < nblocks; b += 32) v0 += part[(size_t)b * REC_STRIDE + c];
+    }
+    sl[sidx][c] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (threadIdx.x < REC_STRIDE) {
         double v = 0;
-        for (int b = lane; b < nblocks; b += 64) v += part[(size_t)c * nblocks + b];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) rec[c] = v;
+        for (int k = 0; k < 32; ++k) v += sl[k][threadIdx.x];
+        rec[threadIdx.x] = threadIdx.x < NREC ? v : 0.0;
     }
     __syncthreads();
 }
@@ -253,6 +329,9 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
 // ------------------------------------------------------------------ fused transform + NN + accumulate
 // MODE 1: point-to-point record (17):  n, sum s[3], sum t[3], sum s t^T[9], sum d2
 // MODE 2: point-to-plane record (30):  n, sum r^2, JtJ upper[21], Jtr[6], sum d2
+// One query per lane (grid.x = ceil(n / 256), grid.y = scans in the batch).  The search
+// runs first with nothing else live in registers; the pair's contribution is formed
+// afterwards and goes straight into the wave reduction.
 template <int MODE, bool WINDOW, bool SHARD>
 __global__ __launch_bounds__(BLK) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                                 int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks)
@@ -261,57 +340,58 @@ __global__ __launch_bounds__(BLK) void k_nn_red(SfGrid g, SfWindow w, const floa
     const int b = blockIdx.y;
     const IcpState *S = st + b;
     if (S->done) return;
-    double T[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = S->T[i];
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    double sx = 0, sy = 0, sz = 0;
+    sf::NNHit hit;
+    hit.j = -1;
+    if (i < n) {
+        const size_t o = (size_t)b * n + i;
+        const double x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
+        sx = S->T[0] * x0 + S->T[1] * y0 + S->T[2] * z0 + S->T[3];
+        sy = S->T[4] * x0 + S->T[5] * y0 + S->T[6] * z0 + S->T[7];
+        sz = S->T[8] * x0 + S->T[9] * y0 + S->T[10] * z0 + S->T[11];
+        const float qx = (float)sx, qy = (float)sy, qz = (float)sz;
+        if (!SHARD || (qx >= xlo && qx < xhi)) hit = sf::nn_search<WINDOW>(g, w, qx, qy, qz, thr);
+    }
     double acc[NREC];
 #pragma unroll
     for (int c = 0; c < NREC; ++c) acc[c] = 0.0;
-    const size_t base = (size_t)b * n;
-    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += nblocks * BLK) {
-        const double x0 = X0x[base + i], y0 = X0y[base + i], z0 = X0z[base + i];
-        const double sx = T[0] * x0 + T[1] * y0 + T[2] * z0 + T[3];
-        const double sy = T[4] * x0 + T[5] * y0 + T[6] * z0 + T[7];
-        const double sz = T[8] * x0 + T[9] * y0 + T[10] * z0 + T[11];
-        const float qx = (float)sx, qy = (float)sy, qz = (float)sz;
-        if (SHARD && !(qx >= xlo && qx < xhi)) continue;
-        const sf::NNHit hit = sf::nn_search<WINDOW>(g, w, qx, qy, qz, thr);
-        if (hit.j < 0) continue;
+    if (hit.j >= 0) {
         const double tx = hit.p.x, ty = hit.p.y, tz = hit.p.z;
         const double ex = sx - tx, ey = sy - ty, ez = sz - tz;
         const double d2 = ex * ex + ey * ey + ez * ez;
         if (MODE == 1) {
-            acc[0] += 1.0;
-            acc[1] += sx; acc[2] += sy; acc[3] += sz;
-            acc[4] += tx; acc[5] += ty; acc[6] += tz;
-            acc[7] += sx * tx; acc[8] += sx * ty; acc[9] += sx * tz;
-            acc[10] += sy * tx; acc[11] += sy * ty; acc[12] += sy * tz;
-            acc[13] += sz * tx; acc[14] += sz * ty; acc[15] += sz * tz;
-            acc[16] += d2;
+            acc[0] = 1.0;
+            acc[1] = sx; acc[2] = sy; acc[3] = sz;
+            acc[4] = tx; acc[5] = ty; acc[6] = tz;
+            acc[7] = sx * tx; acc[8] = sx * ty; acc[9] = sx * tz;
+            acc[10] = sy * tx; acc[11] = sy * ty; acc[12] = sy * tz;
+            acc[13] = sz * tx; acc[14] = sz * ty; acc[15] = sz * tz;
+            acc[16] = d2;
         } else {
             const float4 nf = g.nrm[hit.j];
             const double nx = nf.x, ny = nf.y, nz = nf.z;
             const double r = ex * nx + ey * ny + ez * nz;
-            double J[6] = {sy * nz - sz * ny, sz * nx - sx * nz, sx * ny - sy * nx, nx, ny, nz};
-            acc[0] += 1.0;
-            acc[1] += r * r;
+            const double J[6] = {sy * nz - sz * ny, sz * nx - sx * nz, sx * ny - sy * nx, nx, ny, nz};
+            acc[0] = 1.0;
+            acc[1] = r * r;
             int k = 2;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
 #pragma unroll
-                for (int c = a; c < 6; ++c) { acc[k] += J[a] * J[c]; ++k; }
+                for (int c = a; c < 6; ++c) { acc[k] = J[a] * J[c]; ++k; }
             }
 #pragma unroll
-            for (int a = 0; a < 6; ++a) acc[23 + a] += J[a] * r;
-            acc[29] += d2;
+            for (int a = 0; a < 6; ++a) acc[23 + a] = J[a] * r;
+            acc[29] = d2;
         }
     }
-    block_reduce_store<NREC>(acc, partials + ((size_t)b * NREC) * nblocks + blockIdx.x, nblocks);
+    block_reduce_store<NREC>(acc, partials + ((size_t)b * nblocks + blockIdx.x) * REC_STRIDE);
 }
 
 // ------------------------------------------------------------------ solves (thread 0 of the scan's workgroup)
 // Open3D RegistrationICP loop body after a correspondence search (k-th search, K = max_iteration)
-__device__ void solve_o3d(IcpState *S, const double *rec, int n_src, int k, int K)
+__device__ __forceinline__ void solve_o3d(IcpState *S, const double *rec, int n_src, int k, int K)
 {
     const double n = rec[0];
     const double fitness = n_src > 0 ? n / (double)n_src : 0.0;
@@ -327,16 +407,20 @@ __device__ void solve_o3d(IcpState *S, const double *rec, int n_src, int k, int 
     }
     if (k >= K) { S->done = 1; return; }
     if (n > 0) {
-        double upd[16];
+        double upd[16], Tc[16];
         kabsch_from_record(rec, upd);
-        mat4_mul(upd, S->T, S->T);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Tc[i] = S->T[i];
+        mat4_mul(upd, Tc, Tc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S->T[i] = Tc[i];
     }
     S->iterations += 1;
     S->prev_fitness = fitness;
     S->prev_rmse = rmse;
 }
 
-__device__ void solve_plane(IcpState *S, const double *rec, int n_src, int K)
+__device__ __forceinline__ void solve_plane(IcpState *S, const double *rec, int n_src, int K)
 {
     const double n = rec[0];
     S->fitness = n_src > 0 ? n / (double)n_src : 0.0;
@@ -344,31 +428,40 @@ __device__ void solve_plane(IcpState *S, const double *rec, int n_src, int K)
     S->n_corr = (int)n;
     S->n_research += 1;
     double A[36], rhs[6], x[6];
-    int k = 2;
-    for (int a = 0; a < 6; ++a)
-        for (int c = a; c < 6; ++c) { A[6 * a + c] = rec[k]; A[6 * c + a] = rec[k]; ++k; }
+    {
+        int k = 2;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = a; c < 6; ++c) { A[6 * a + c] = rec[k]; A[6 * c + a] = rec[k]; ++k; }
+    }
+#pragma unroll
     for (int a = 0; a < 6; ++a) rhs[a] = -rec[23 + a];
     if (n < 6 || ldlt6(A, rhs, x) != 0) {
         S->flags |= SF_ICP_FLAG_SINGULAR;
         S->done = 1;
         return;
     }
-    double upd[16];
+    double upd[16], Tc[16];
     vec6_to_mat4(x, upd);
-    mat4_mul(upd, S->T, S->T);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Tc[i] = S->T[i];
+    mat4_mul(upd, Tc, Tc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S->T[i] = Tc[i];
     S->iterations += 1;
     if (S->iterations >= K) { S->converged = 1; S->done = 1; }
 }
 
 template <int MODE>
-__global__ __launch_bounds__(BLK) void k_reduce_solve(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, int n_src, int k, int K)
+__global__ __launch_bounds__(RBLK) void k_reduce_solve(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, int n_src, int k, int K)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x;
     IcpState *S = st + b;
     if (S->done) return;
     __shared__ double rec[REC_STRIDE];
-    reduce_partials<NREC>(partials + ((size_t)b * NREC) * nblocks, nblocks, rec);
+    reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, nblocks, rec);
     if (threadIdx.x == 0) {
         for (int c = 0; c < NREC; ++c) S->rec[c] = rec[c];
         if (MODE == 1) solve_o3d(S, rec, n_src, k, K);
@@ -378,7 +471,7 @@ __global__ __launch_bounds__(BLK) void k_reduce_solve(IcpState *__restrict__ st,
 
 // multi-GPU split: reduce into the exchange buffer, all-reduce outside, then solve
 template <int MODE>
-__global__ __launch_bounds__(BLK) void k_reduce_only(const IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, double *__restrict__ xchg)
+__global__ __launch_bounds__(RBLK) void k_reduce_only(const IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, double *__restrict__ xchg)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x;
@@ -387,8 +480,8 @@ __global__ __launch_bounds__(BLK) void k_reduce_only(const IcpState *__restrict_
         if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = 0.0;
         return;
     }
-    reduce_partials<NREC>(partials + ((size_t)b * NREC) * nblocks, nblocks, rec);
-    if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = threadIdx.x < NREC ? rec[threadIdx.x] : 0.0;
+    reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, nblocks, rec);
+    if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = rec[threadIdx.x];
 }
 
 template <int MODE>
@@ -400,7 +493,10 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
     IcpState *S = st + b;
     if (S->done) return;
     double rec[REC_STRIDE];
-    for (int c = 0; c < NREC; ++c) { rec[c] = xchg[(size_t)b * REC_STRIDE + c]; S->rec[c] = rec[c]; }
+#pragma unroll
+    for (int c = 0; c < REC_STRIDE; ++c) rec[c] = c < NREC ? xchg[(size_t)b * REC_STRIDE + c] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NREC; ++c) S->rec[c] = rec[c];
     if (MODE == 1) solve_o3d(S, rec, n_src, k, K);
     else solve_plane(S, rec, n_src, K);
 }
@@ -484,21 +580,26 @@ __global__ __launch_bounds__(BLK) void k_ref_red(const float4 *__restrict__ pts,
         acc[13] += sz * tx; acc[14] += sz * ty; acc[15] += sz * tz;
         acc[16] += (double)nrm;
     }
-    block_reduce_store<NREC_P2P>(acc, partials + ((size_t)b * NREC_P2P) * nblocks + blockIdx.x, nblocks);
+    block_reduce_store<NREC_P2P>(acc, partials + ((size_t)b * nblocks + blockIdx.x) * REC_STRIDE);
 }
 
 // step = Kabsch(record); T <- step * T in float32 (icp_point_to_point.cpp:226-228)
-__device__ void ref_take_step(IcpState *S, const double *rec, float error)
+__device__ __forceinline__ void ref_take_step(IcpState *S, const double *rec, float error)
 {
     double upd[16];
     kabsch_from_record(rec, upd);
     float sf[16], Tf[16], Tn[16];
+#pragma unroll
     for (int i = 0; i < 16; ++i) { sf[i] = (float)upd[i]; Tf[i] = (float)S->T[i]; }
+#pragma unroll
     for (int r = 0; r < 4; ++r)
+#pragma unroll
         for (int c = 0; c < 4; ++c)
             Tn[4 * r + c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(sf[4 * r], Tf[c]), __fmul_rn(sf[4 * r + 1], Tf[4 + c])), __fmul_rn(sf[4 * r + 2], Tf[8 + c])),
                                       __fmul_rn(sf[4 * r + 3], Tf[12 + c]));
+#pragma unroll
     for (int i = 0; i < 16; ++i) S->T[i] = Tn[i];
+#pragma unroll
     for (int i = 0; i < 12; ++i) S->step[i] = sf[i];
     S->step_pending = 1;
     S->last_error = error;
@@ -507,14 +608,14 @@ __device__ void ref_take_step(IcpState *S, const double *rec, float error)
 
 // phase 0: after the initial search (cpp:195-200); phase 1: top of loop iteration
 // (cpp:209-224); phase 2: after a lazy re-search (cpp:223-226)
-__global__ __launch_bounds__(BLK) void k_ref_decide(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, IcpParams prm, int phase)
+__global__ __launch_bounds__(RBLK) void k_ref_decide(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, IcpParams prm, int phase)
 {
     const int b = blockIdx.x;
     IcpState *S = st + b;
     if (S->done) return;
     if (phase == 2 && !S->research) return;
     __shared__ double rec[REC_STRIDE];
-    reduce_partials<NREC_P2P>(partials + ((size_t)b * NREC_P2P) * nblocks, nblocks, rec);
+    reduce_partials<NREC_P2P>(partials + (size_t)b * nblocks * REC_STRIDE, nblocks, rec);
     if (threadIdx.x != 0) return;
     for (int c = 0; c < NREC_P2P; ++c) S->rec[c] = rec[c];
     const double n = rec[0];
@@ -594,8 +695,8 @@ int icp_alloc(sf_icp *icp, int64_t n, int batch)
     SF_TRY(icp->X0.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
     SF_TRY(icp->state.reserve(sizeof(IcpState) * (size_t)batch));
     SF_TRY(icp->d_inits.reserve(sizeof(double) * 16 * (size_t)batch));
-    icp->nblocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, sf::div_up(n, BLK)));
-    SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)NREC_PLANE * (size_t)icp->nblocks * (size_t)batch));
+    icp->nblocks = (int)std::max<int64_t>(1, sf::div_up(n, BLK));
+    SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)REC_STRIDE * (size_t)icp->nblocks * (size_t)batch));
     SF_TRY(icp->xchg_own.reserve(sizeof(double) * REC_STRIDE * (size_t)batch));
     if (icp->batch != batch || icp->inits.size() != (size_t)batch * 16) {
         icp->inits.assign((size_t)batch * 16, 0.0);
@@ -696,12 +797,12 @@ int enqueue_align(sf_icp *icp, int mode)
     if (mode == SF_ICP_O3D_P2P) {
         for (int k = 0; k <= K; ++k) {
             launch_nn_red<1>(icp);
-            hipLaunchKernelGGL(k_reduce_solve<1>, dim3(B), dim3(BLK), 0, s, st, part, icp->nblocks, n, k, K);
+            hipLaunchKernelGGL(k_reduce_solve<1>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks, n, k, K);
         }
     } else if (mode == SF_ICP_P2PLANE) {
         for (int k = 0; k < K; ++k) {
             launch_nn_red<2>(icp);
-            hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(BLK), 0, s, st, part, icp->nblocks, n, k, K);
+            hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks, n, k, K);
         }
     } else {
         const int64_t total = icp->n * B;
@@ -720,7 +821,7 @@ int enqueue_align(sf_icp *icp, int mode)
         auto red = [&](int apply, int only_research) {
             hipLaunchKernelGGL(k_ref_red, gred, dim3(BLK), 0, s, m->grid.pts, Xx, Xy, Xz, n, st, corr, apply, only_research, part, icp->nblocks);
         };
-        auto decide = [&](int phase) { hipLaunchKernelGGL(k_ref_decide, dim3(B), dim3(BLK), 0, s, st, part, icp->nblocks, icp->prm, phase); };
+        auto decide = [&](int phase) { hipLaunchKernelGGL(k_ref_decide, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks, icp->prm, phase); };
         hipLaunchKernelGGL(k_ref_init, gpts, dim3(BLK), 0, s, soa(icp->X0, total, 0), soa(icp->X0, total, 1), soa(icp->X0, total, 2), n, st, Xx, Xy, Xz, corr);
         nn(1);
         red(0, 0);
@@ -1000,10 +1101,10 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
     hipStream_t s = icp->ctx->stream;
     if (mode == SF_ICP_O3D_P2P) {
         launch_nn_red<1>(icp);
-        hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(BLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), icp->nblocks, x);
+        hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), icp->nblocks, x);
     } else {
         launch_nn_red<2>(icp);
-        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(BLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), icp->nblocks, x);
+        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), icp->nblocks, x);
     }
     SF_HIP(hipGetLastError());
     return SF_OK;

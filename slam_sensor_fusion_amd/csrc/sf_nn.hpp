@@ -6,6 +6,10 @@
 // One lane per query.  The map is sorted by cell (x fastest), so the 2R+1 cells of one
 // (y,z) row are ONE contiguous candidate range: a (2R+1)^3 block costs (2R+1)^2 range
 // look-ups, each followed by 16-byte candidate loads (x, y, z, original index).
+// The path is latency-bound (random 16-byte gathers served by L2 / Infinity Cache), so
+// the code is written for memory-level parallelism: the centre row first (it usually
+// holds the answer and prunes the rest), then the range bounds of all surviving rows in
+// one batch of independent loads, candidates fetched four at a time.
 // Exactness: after scanning the block of radius R around the query's cell, every
 // unscanned point is at least m = distance(query, block boundary) away; the search stops
 // when best <= m^2 (best starts at the acceptance threshold, so "nothing acceptable
@@ -48,18 +52,31 @@ __device__ __forceinline__ bool window_accepts(const SfWindow &w, float px, floa
 }
 
 template <bool WINDOW>
+__device__ __forceinline__ void consider(const SfWindow &w, const float4 &p, uint32_t j, bool valid, float qx, float qy, float qz, NNHit &hit)
+{
+    const float d2 = l2_simple(qx, qy, qz, p.x, p.y, p.z);
+    if (valid && d2 < hit.d2) {
+        if (!WINDOW || window_accepts(w, p.x, p.y, p.z)) {
+            hit.d2 = d2;
+            hit.j = (int)j;
+            hit.p = p;
+        }
+    }
+}
+
+// candidates [a, b), four independent 16-byte loads in flight per step (indices clamped
+// into the range, the tail is masked)
+template <bool WINDOW>
 __device__ __forceinline__ void scan_range(const SfGrid &g, const SfWindow &w, uint32_t a, uint32_t b, float qx, float qy, float qz, NNHit &hit)
 {
-    for (uint32_t j = a; j < b; ++j) {
-        float4 p = g.pts[j];
-        float d2 = l2_simple(qx, qy, qz, p.x, p.y, p.z);
-        if (d2 < hit.d2) {
-            if (!WINDOW || window_accepts(w, p.x, p.y, p.z)) {
-                hit.d2 = d2;
-                hit.j = (int)j;
-                hit.p = p;
-            }
-        }
+    for (uint32_t j = a; j < b; j += 4) {
+        const uint32_t last = b - 1;
+        const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
+        const float4 p0 = g.pts[j], p1 = g.pts[j1], p2 = g.pts[j2], p3 = g.pts[j3];
+        consider<WINDOW>(w, p0, j, true, qx, qy, qz, hit);
+        consider<WINDOW>(w, p1, j1, j + 1 < b, qx, qy, qz, hit);
+        consider<WINDOW>(w, p2, j2, j + 2 < b, qx, qy, qz, hit);
+        consider<WINDOW>(w, p3, j3, j + 3 < b, qx, qy, qz, hit);
     }
 }
 
@@ -92,24 +109,38 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
 
     for (int R = 1; R <= rcap; ++R) {
         const int x0 = max(cx - R, 0), x1 = min(cx + R, nx - 1);
-        const int y0 = max(cy - R, 0), y1 = min(cy + R, ny - 1);
-        const int z0 = max(cz - R, 0), z1 = min(cz + R, nz - 1);
         if (R == 1) {
-            // centre row first, then face rows, then corner rows: best shrinks early and
-            // prunes most of the remaining rows
-            const int oy[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
-            const int oz[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int y = cy + oy[k], z = cz + oz[k];
-                if (y < 0 || y >= ny || z < 0 || z >= nz) continue;
-                const float ry = cell_gap(gy, y, cy) * h, rz = cell_gap(gz, z, cz) * h;
-                if ((ry * ry + rz * rz) * 0.998f >= hit.d2) continue;
-                const size_t row = ((size_t)z * ny + y) * nx;
+            // centre row first: it usually holds the answer and prunes most other rows
+            {
+                const size_t row = ((size_t)cz * ny + cy) * nx;
                 const uint32_t a = g.cell_start[row + x0], b = g.cell_start[row + x1 + 1];
                 scan_range<WINDOW>(g, w, a, b, qx, qy, qz, hit);
             }
+            // face rows then corner rows; bounds of every surviving row fetched together
+            const int oy[8] = {-1, 1, 0, 0, -1, 1, -1, 1};
+            const int oz[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+            uint32_t ra[8], rb[8];
+            float gap2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int y = cy + oy[k], z = cz + oz[k];
+                const bool inside = y >= 0 && y < ny && z >= 0 && z < nz;
+                const float ry = cell_gap(gy, y, cy) * h, rz = cell_gap(gz, z, cz) * h;
+                gap2[k] = inside ? (ry * ry + rz * rz) * 0.998f : 3.0e38f;
+                ra[k] = 0;
+                rb[k] = 0;
+                if (gap2[k] < hit.d2) {
+                    const size_t row = ((size_t)z * ny + y) * nx;
+                    ra[k] = g.cell_start[row + x0];
+                    rb[k] = g.cell_start[row + x1 + 1];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (gap2[k] < hit.d2) scan_range<WINDOW>(g, w, ra[k], rb[k], qx, qy, qz, hit);
         } else {
+            const int y0 = max(cy - R, 0), y1 = min(cy + R, ny - 1);
+            const int z0 = max(cz - R, 0), z1 = min(cz + R, nz - 1);
             for (int z = z0; z <= z1; ++z) {
                 const float rz = cell_gap(gz, z, cz) * h;
                 for (int y = y0; y <= y1; ++y) {
