@@ -51,6 +51,15 @@ def load_library():
             "libslamfusion.so not found at %s — build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    # This image carries two HIP runtimes (ROCm 7.2 under /opt/rocm, and the 7.0 one bundled
+    # in the torch wheel).  A process must use exactly one: import torch FIRST so that the
+    # library's libamdhip64.so.7 dependency resolves to the runtime torch already loaded
+    # (the other order leaves torch with "No HIP GPUs are available").  torch is plumbing
+    # only (streams, RCCL); nothing in the data path goes through it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.sf_last_error.restype = C.c_char_p
     lib.sf_ctx_stream.restype = C.c_void_p

@@ -1,0 +1,106 @@
+"""BASELINE.json full sizes on the GPU (200k-pt scans vs 2M / 10M-pt maps).  The oracle
+needs minutes at these sizes, so these tests use size-independent properties of the domain:
+voxel ids strictly ascending and consistent with their centroids, NN idempotence on map
+points, NN vs brute force on a sample, registration recovering the generating transform,
+batched == single, and a bounded oracle spot check."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world_2m(api, ctx, synth):
+    raw = synth.make_map(2_000_000)
+    c = api.Cloud(ctx, raw)
+    c.voxel_downsample(0.1, "pcl")
+    ids = c.voxel_out_ids()
+    pid = c.voxel_point_ids()
+    ds = c.download()
+    mp = api.Map(ctx, c, 0.25)
+    mp.estimate_normals(0.25)
+    return dict(raw=raw, map=ds, ids=ids, pid=pid, mp=mp)
+
+
+def test_voxel_properties_2m(world_2m):
+    raw, ds, ids, pid = world_2m["raw"], world_2m["map"], world_2m["ids"], world_2m["pid"]
+    assert (np.diff(ids.astype(np.int64)) > 0).all()                    # ascending, unique
+    assert np.array_equal(np.unique(pid), ids)                          # one output per occupied voxel
+    assert 0.94 < len(ds) / len(raw) < 0.96                             # ~95 % survive at 100 pts/m^3
+    # PCL's index formula recomputed on the host in float32 (closed form, no oracle)
+    inv = np.float32(1.0) / np.float32(0.1)
+    ijk = np.floor(raw * inv)
+    mn = np.floor(raw.min(0) * inv)
+    d = (np.floor(raw.max(0) * inv) - mn + 1).astype(np.int64)
+    lin = ((ijk - mn).astype(np.int64) * [1, d[0], d[0] * d[1]]).sum(1)
+    assert np.array_equal(lin, pid.astype(np.int64))
+    # every centroid lies in its own voxel (up to float32 rounding at the faces)
+    cijk = np.floor(ds * inv) - mn
+    clin = (cijk.astype(np.int64) * [1, d[0], d[0] * d[1]]).sum(1)
+    assert (clin == ids).mean() > 0.9999
+    # float64 mean per voxel agrees with the float32 sequential centroid
+    sums = np.zeros((len(ids), 3))
+    pos = np.searchsorted(ids, pid)
+    np.add.at(sums, pos, raw.astype(np.float64))
+    cnt = np.bincount(pos, minlength=len(ids))
+    assert np.abs(sums / cnt[:, None] - ds).max() < 1e-4
+
+
+def test_nn_properties_2m(api, ctx, orc, synth, world_2m):
+    ds, mp = world_2m["map"], world_2m["mp"]
+    rng = np.random.default_rng(0)
+    pick = rng.choice(len(ds), 200_000, replace=False)
+    idx, d2 = mp.nn(ds[pick])
+    assert (d2 == 0).all()                                              # idempotence: a map point is its own NN
+    assert (idx == pick).mean() > 0.9999
+    scan, src = synth.make_scan(ds, 200_000)
+    q = (scan.astype(np.float64) @ synth.t_true()[:3, :3].T + synth.t_true()[:3, 3]).astype(np.float32)
+    gi, gd = mp.nn(q)
+    assert (gi == src).mean() > 0.97                                    # 1 cm noise: almost always the generating point
+    sub = rng.choice(len(q), 3000, replace=False)
+    oi, od = orc.KdTreeF(ds).nn(q[sub])                                 # bounded oracle spot check
+    assert np.array_equal(gd[sub], od) and (gi[sub] == oi).mean() > 0.999
+
+
+def test_registration_200k_vs_2m(api, ctx, synth, world_2m):
+    ds, mp = world_2m["map"], world_2m["mp"]
+    scans = np.stack([synth.make_scan(ds, 200_000, scan_id=k)[0] for k in range(2)])
+    icp = api.Icp(ctx, 0.5, 20, 0.05, 1e-5)
+    icp.set_target(mp)
+    icp.set_source_batch(scans)
+    icp.set_initial_batch(None)
+    res = icp.align_batch("p2plane")
+    for r in res:
+        dt, dr = synth.pose_error(r["T64"], synth.t_true())
+        assert r["iterations"] == 20 and r["fitness"] > 0.999
+        assert dt < 2e-4 and dr < 1e-5                                  # 200k points: noise floor ~ sigma / sqrt(N)
+    icp.set_source(scans[1])
+    single = icp.align("p2plane")
+    assert np.array_equal(single["T64"], res[1]["T64"])                 # batched == single, bitwise
+    icp.set_num_iterations(30)
+    r = icp.align("o3d_p2p")
+    dt, dr = synth.pose_error(r["T64"], synth.t_true())
+    assert r["converged"] and dt < 2e-4 and dr < 1e-5
+    icp.set_num_iterations(10)
+    icp.set_acceptable_mean_error(0.001)
+    r = icp.align("ref_cpp")
+    dt, dr = synth.pose_error(r["T64"], synth.t_true())
+    assert r["iterations"] == 10 and dt < 2e-3 and dr < 1e-4
+
+
+def test_registration_200k_vs_10m(api, ctx, synth):
+    raw = synth.make_map(10_000_000)
+    c = api.Cloud(ctx, raw)
+    del raw
+    c.voxel_downsample(0.1, "pcl")
+    ds = c.download()
+    assert 9.4e6 < len(ds) < 9.6e6
+    mp = api.Map(ctx, c, 0.25)
+    mp.estimate_normals(0.25)
+    scan, _ = synth.make_scan(ds, 200_000)
+    icp = api.Icp(ctx, 0.5, 20, 0.05, 1e-5)
+    icp.set_target(mp)
+    icp.set_source(scan)
+    r = icp.align("p2plane")
+    dt, dr = synth.pose_error(r["T64"], synth.t_true())
+    assert r["iterations"] == 20 and r["fitness"] > 0.999 and dt < 2e-4 and dr < 1e-5
