@@ -120,6 +120,9 @@ int sf_map_cell_size(sf_map *m, float *cell, int32_t dims[3]);
 int sf_map_window_none(sf_map *m);
 int sf_map_window_sphere(sf_map *m, const float center[3], double radius);
 int sf_map_window_obb(sf_map *m, const double center[3], const double R[9], const double extent[3]);
+/* number of indexed map points inside the current window (the reference skips the scan when
+ * its cropped map is empty, localization_node.py:226-228) */
+int sf_map_window_count(sf_map *m, int64_t *n);
 /* extension x2 (no reference code): PCA normals from neighbours within `radius` */
 int sf_map_estimate_normals(sf_map *m, float radius);
 int sf_map_set_normals(sf_map *m, const float *normals, int64_t n); /* original point order */

@@ -3,8 +3,10 @@
 There is no CPU fallback: if the HIP library is missing or no device is present every
 entry point raises.  Nothing here imports or calls anything under oracle/.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -39,6 +41,19 @@ class IcpResult(C.Structure):
 
 
 _lib = None
+_live = weakref.WeakSet()   # every wrapper object, closed in dependency order at exit
+
+
+def _close_all():
+    for kind in ("Icp", "Map", "Cloud", "Context"):
+        for obj in [o for o in list(_live) if type(o).__name__ == kind]:
+            try:
+                obj.close()
+            except Exception:
+                pass
+
+
+atexit.register(_close_all)
 
 
 def load_library():
@@ -96,6 +111,7 @@ class Context:
         self.lib = load_library()
         self.h = C.c_void_p()
         _check(self.lib.sf_ctx_create(C.c_int(device), C.c_void_p(stream), C.byref(self.h)))
+        _live.add(self)
 
     def synchronize(self):
         _check(self.lib.sf_ctx_synchronize(self.h))
@@ -128,6 +144,7 @@ class Cloud:
         self.ctx, self.lib = ctx, ctx.lib
         self.h = C.c_void_p()
         _check(self.lib.sf_cloud_create(ctx.h, C.byref(self.h)))
+        _live.add(self)
         if xyz is not None:
             self.upload(xyz)
 
@@ -242,6 +259,7 @@ class Map:
         self.ctx, self.lib = ctx, ctx.lib
         self.h = C.c_void_p()
         _check(self.lib.sf_map_create(ctx.h, C.byref(self.h)))
+        _live.add(self)
         if cloud is not None:
             self.build(cloud, cell)
 
@@ -272,6 +290,11 @@ class Map:
     def window_obb(self, center, R, extent):
         c, R, e = _f64(center), _f64(R).reshape(3, 3), _f64(extent)
         _check(self.lib.sf_map_window_obb(self.h, _p(c), _p(R), _p(e)))
+
+    def window_count(self):
+        n = C.c_int64()
+        _check(self.lib.sf_map_window_count(self.h, C.byref(n)))
+        return n.value
 
     def estimate_normals(self, radius):
         _check(self.lib.sf_map_estimate_normals(self.h, C.c_float(radius)))
@@ -318,6 +341,7 @@ class Icp:
         _check(self.lib.sf_icp_create(ctx.h, C.c_float(max_correspondence_dist), C.c_int(num_iterations),
                                       C.c_float(acceptable_mean_error), C.c_float(transformation_epsilon),
                                       C.byref(self.h)))
+        _live.add(self)
 
     def set_max_correspondence_dist(self, v):
         _check(self.lib.sf_icp_set_max_correspondence_dist(self.h, C.c_float(v)))

@@ -53,9 +53,8 @@ extern "C" int sf_ctx_create(int device_id, void *hip_stream, sf_ctx **out)
     return SF_OK;
 }
 
-extern "C" void sf_ctx_destroy(sf_ctx *ctx)
+static void ctx_free(sf_ctx *ctx)
 {
-    if (!ctx) return;
     hipError_t e = hipStreamSynchronize(ctx->stream);
     (void)e;
     ctx->scratch.release();
@@ -63,6 +62,27 @@ extern "C" void sf_ctx_destroy(sf_ctx *ctx)
     if (ctx->h_pinned) { e = hipHostFree(ctx->h_pinned); (void)e; }
     if (ctx->own_stream) { e = hipStreamDestroy(ctx->stream); (void)e; }
     delete ctx;
+}
+
+namespace sf {
+void ctx_retain(sf_ctx *ctx) { ctx->refs += 1; }
+void ctx_release(sf_ctx *ctx)
+{
+    ctx->refs -= 1;
+    if (ctx->zombie && ctx->refs <= 0) ctx_free(ctx);
+}
+} // namespace sf
+
+extern "C" void sf_ctx_destroy(sf_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->refs > 0) { // children still alive: the last one to go frees the context
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        (void)e;
+        ctx->zombie = true;
+        return;
+    }
+    ctx_free(ctx);
 }
 
 extern "C" void *sf_ctx_stream(sf_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
@@ -88,6 +108,7 @@ extern "C" int sf_cloud_create(sf_ctx *ctx, sf_cloud **out)
     sf_cloud *c = new (std::nothrow) sf_cloud();
     SF_CHECK(c, SF_ERR_NOMEM, "out of host memory");
     c->ctx = ctx;
+    sf::ctx_retain(ctx);
     *out = c;
     return SF_OK;
 }
@@ -99,7 +120,9 @@ extern "C" void sf_cloud_destroy(sf_cloud *c)
     (void)e;
     c->xyz.release(); c->last_idx.release(); c->vox_point_ids.release();
     c->vox_out_ids.release(); c->vox_out_means.release();
+    sf_ctx *ctx = c->ctx;
     delete c;
+    sf::ctx_release(ctx);
 }
 
 static void cloud_reset_meta(sf_cloud *c)

@@ -85,6 +85,8 @@ struct sf_ctx {
     sf::DevBuf scratch;   // rocPRIM temporary storage
     sf::DevBuf scratch2;  // block counts / small reductions
     void *h_pinned = nullptr; // small pinned staging (4 KiB)
+    int refs = 0;          // live clouds / maps / icps created on this context
+    bool zombie = false;   // sf_ctx_destroy was called while children were alive
 };
 
 // AoS xyz float32 point set on the device
@@ -134,6 +136,9 @@ namespace sf {
 // device-side helpers implemented in sf_cloud.hip, used across TUs
 int compact_cloud(sf_cloud *c, const uint8_t *d_flags);
 int ensure_scratch(sf_ctx *ctx, size_t bytes);
+// children keep their context alive: any destruction order is safe
+void ctx_retain(sf_ctx *ctx);
+void ctx_release(sf_ctx *ctx);
 struct MinMaxHost { float mn[3], mx[3]; int64_t n_finite; };
 // min/max over the finite points of a device AoS cloud (synchronises the stream)
 int cloud_minmax(sf_ctx *ctx, const float *d_xyz, int64_t n, MinMaxHost *out);

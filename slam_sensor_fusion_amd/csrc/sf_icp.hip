@@ -880,6 +880,7 @@ extern "C" int sf_icp_create(sf_ctx *ctx, float max_correspondence_dist, int num
     sf_icp *icp = new (std::nothrow) sf_icp();
     SF_CHECK(icp, SF_ERR_NOMEM, "out of host memory");
     icp->ctx = ctx;
+    sf::ctx_retain(ctx);
     icp->prm.max_corr = max_correspondence_dist;
     icp->prm.num_iters = num_iterations;
     icp->prm.accept = acceptable_mean_error;
@@ -899,7 +900,9 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     icp->partials.release(); icp->xchg_own.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
+    sf_ctx *ctx = icp->ctx;
     delete icp;
+    sf::ctx_release(ctx);
 }
 
 extern "C" int sf_icp_set_max_correspondence_dist(sf_icp *icp, float v) { SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL"); icp->prm.max_corr = v; return SF_OK; }

@@ -84,6 +84,7 @@ extern "C" int sf_map_create(sf_ctx *ctx, sf_map **out)
     sf_map *m = new (std::nothrow) sf_map();
     SF_CHECK(m, SF_ERR_NOMEM, "out of host memory");
     m->ctx = ctx;
+    sf::ctx_retain(ctx);
     *out = m;
     return SF_OK;
 }
@@ -95,7 +96,9 @@ extern "C" void sf_map_destroy(sf_map *m)
     (void)e;
     m->pts4.release(); m->nrm4.release(); m->cell_start.release(); m->keys.release(); m->vals.release();
     m->keys2.release(); m->vals2.release(); m->inv_perm.release();
+    sf_ctx *ctx = m->ctx;
     delete m;
+    sf::ctx_release(ctx);
 }
 
 extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
@@ -224,6 +227,37 @@ extern "C" int sf_map_window_obb(sf_map *m, const double center[3], const double
     m->window.kind = 2;
     for (int d = 0; d < 3; ++d) { m->window.oc[d] = center[d]; m->window.ohalf[d] = extent[d] / 2; }
     for (int k = 0; k < 9; ++k) m->window.oR[k] = R[k];
+    return SF_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_window_count(SfGrid g, SfWindow w, unsigned long long *__restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool in = false;
+    if (j < g.n) {
+        const float4 p = g.pts[j];
+        in = sf::window_accepts(w, p.x, p.y, p.z);
+    }
+    const unsigned long long b = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b)); // integer: order independent
+}
+} // namespace
+
+extern "C" int sf_map_window_count(sf_map *m, int64_t *n)
+{
+    SF_CHECK(m && m->built && n, SF_ERR_STATE, "map not built");
+    sf_ctx *ctx = m->ctx;
+    SF_HIP(hipSetDevice(ctx->device));
+    if (m->window.kind == 0 || m->grid.n == 0) { *n = m->grid.n; return SF_OK; }
+    SF_TRY(ctx->scratch2.reserve(sizeof(unsigned long long)));
+    unsigned long long *d = ctx->scratch2.as<unsigned long long>();
+    SF_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_window_count, dim3(nblk(m->grid.n)), dim3(256), 0, ctx->stream, m->grid, m->window, d);
+    unsigned long long *h = reinterpret_cast<unsigned long long *>(ctx->h_pinned);
+    SF_HIP(hipMemcpyAsync(h, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
+    *n = (int64_t)h[0];
     return SF_OK;
 }
 

@@ -1,0 +1,86 @@
+"""The C++ node's per-scan orchestration (localization/src/localization_node.cpp:263-344)
+over the C ABI: same order, same constants, same state variables — minus the ROS 2 shell
+(rclcpp, message_filters, publishers: out of scope) and minus the
+start-up BruteForceAlignment (a §8(f-1) "next" row; callers pass the initial lock).
+
+Host work (a14-a18, microseconds) runs in libslamfusion's C++ fusion functions; device
+work is subsample -> radius crop -> (window change) -> ICP.  The reference re-crops the map and
+rebuilds a FLANN tree every 3 m of travel (:299-305); here that is only a new window on the
+resident whole-map index.
+"""
+import numpy as np
+
+from . import api
+
+
+class LocalizationFlow:
+    # localization_node.h:142,145 and localization_node.cpp:19-35
+    ref_frame_distance_ = 3.0
+    cloud_crop_radius_ = 10.0
+
+    def __init__(self, ctx, map_points, map_T_global, altitude_table=None, map_is_downsampled=True):
+        self.ctx = ctx
+        cloud = api.Cloud(ctx, np.asarray(map_points, dtype=np.float32))
+        if not map_is_downsampled:
+            cloud.voxel_downsample(0.1, "pcl")              # getMapCloud(0.1f), :19
+        cloud.subsample(3)                                   # applyUniformSubsample(map_cloud_, 3), :20
+        self.map_cloud_ = cloud
+        self.map_index_ = api.Map(ctx, cloud, 0.0)
+        self.map_T_global_ = np.asarray(map_T_global, dtype=np.float64)
+        self.altitude_table_ = np.zeros((0, 3)) if altitude_table is None else np.asarray(altitude_table, dtype=np.float64)
+        self.icp_ = api.Icp(ctx, 0.5, 10, 0.05, 1e-5)        # :24-28
+        self.icp_.set_target(self.map_index_)
+        self.coarse_pose_filter_ = api.StochasticFilter(4, 3.0)   # :32-34
+        self.map_T_sensor_ = np.eye(4, dtype=np.float32)
+        self.odom_T_sensor_previous_ = np.eye(4, dtype=np.float32)
+        self.map_T_ref_ = np.eye(4, dtype=np.float32)
+        self.have_window_ = False
+        self.current_compass_yaw_ = 0.0
+        self.first_time_ = True
+        self.last = {}
+
+    def compassCallback(self, compass_deg):                  # :62-77
+        self.current_compass_yaw_ = api.compass_to_yaw(compass_deg)
+
+    def computeGpsCoarsePoseInMapFrame(self, lat, lon):      # :112-128
+        alt = api.closest_altitude(self.altitude_table_, lat, lon)
+        return api.gps_pose(self.map_T_global_, self.current_compass_yaw_, lat, lon, alt)
+
+    def localizationCallback(self, scan_xyz, gps, odom):
+        """gps = dict(latitude, longitude, altitude, position_covariance[9]);
+        odom = dict(q_wxyz, t, covariance[36]).  Returns map_T_sensor or None when gated."""
+        if gps["altitude"] < 0:                              # :269-276
+            return None
+        odom_T_sensor_current = api.quat_to_pose(odom["q_wxyz"], odom["t"])
+        if self.first_time_:                                 # :278-283 -> :181-198
+            self.map_T_sensor_ = self.computeGpsCoarsePoseInMapFrame(gps["latitude"], gps["longitude"])
+            self.map_T_ref_ = self.map_T_sensor_.copy()
+            self.odom_T_sensor_previous_ = odom_T_sensor_current
+            self.first_time_ = False
+            return None
+
+        # PREPROCESSING :290-305
+        scan = api.Cloud(self.ctx, scan_xyz)
+        scan.subsample(2)
+        scan.crop_radius([0.0, 0.0, 0.0], self.cloud_crop_radius_, sorted=True)
+        sensor_T_ref = api.mat4f_mul(api.mat4f_inverse(self.map_T_sensor_), self.map_T_ref_)
+        if np.linalg.norm(sensor_T_ref[:3, 3].astype(np.float32)) > self.ref_frame_distance_ or not self.have_window_:
+            self.map_index_.window_sphere(self.map_T_sensor_[:3, 3], self.cloud_crop_radius_)
+            self.map_T_ref_ = self.map_T_sensor_.copy()
+            self.have_window_ = True
+
+        # FINE ALIGNMENT :318-338
+        map_T_sensor_odom = api.odom_prediction(self.map_T_sensor_, self.odom_T_sensor_previous_, odom_T_sensor_current)
+        map_T_sensor_gps = self.computeGpsCoarsePoseInMapFrame(gps["latitude"], gps["longitude"])
+        odometry_gain, gps_compass_gain = api.pose_gains(gps["position_covariance"], odom["covariance"], fixed=False)
+        prior = api.blend(odometry_gain, map_T_sensor_odom, gps_compass_gain, map_T_sensor_gps)
+        self.coarse_pose_filter_.addPoseToQueue(prior)
+        prior = self.coarse_pose_filter_.applyGaussianFilterToCurrentPose(self.map_T_sensor_, prior)
+        self.icp_.set_source(scan)
+        self.icp_.set_initial_transformation(prior.astype(np.float32))
+        result = self.icp_.align("ref_cpp")
+        self.map_T_sensor_ = result["T"]                     # no has_converged check, :338
+        self.odom_T_sensor_previous_ = odom_T_sensor_current  # :341
+        self.last = dict(prior=prior, odom=map_T_sensor_odom, gps=map_T_sensor_gps, icp=result,
+                         gains=(odometry_gain, gps_compass_gain), n_scan=len(scan))
+        return self.map_T_sensor_
