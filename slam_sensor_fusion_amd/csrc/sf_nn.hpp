@@ -116,28 +116,61 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
                 const uint32_t a = g.cell_start[row + x0], b = g.cell_start[row + x1 + 1];
                 scan_range<WINDOW>(g, w, a, b, qx, qy, qz, hit);
             }
-            // face rows then corner rows; bounds of every surviving row fetched together
-            const int oy[8] = {-1, 1, 0, 0, -1, 1, -1, 1};
-            const int oz[8] = {0, 0, -1, 1, -1, -1, 1, 1};
-            uint32_t ra[8], rb[8];
-            float gap2[8];
+            // The 8 neighbouring rows (faces first, then corners).  Which of them a query still
+            // needs depends on where it sits inside its cell, so the row is per-LANE data: every
+            // lane walks only its own needed rows (a bit mask), the wave iterates
+            // max-over-lanes(popcount) times instead of 8, and the range bounds of a lane's
+            // next row are requested before its current row is scanned.
+            // row k: dy = OY(k) - 1, dz = OZ(k) - 1 with 2-bit fields packed in constants
+            //   k      0   1   2   3   4   5   6   7
+            //   dy    -1  +1   0   0  -1  +1  -1  +1
+            //   dz     0   0  -1  +1  -1  -1  +1  +1
+            constexpr uint32_t OYP = 0u | (2u << 2) | (1u << 4) | (1u << 6) | (0u << 8) | (2u << 10) | (0u << 12) | (2u << 14);
+            constexpr uint32_t OZP = 1u | (1u << 2) | (0u << 4) | (2u << 6) | (0u << 8) | (0u << 10) | (2u << 12) | (2u << 14);
+            // gaps to the four neighbouring slabs (in metres, >= 0); corner gap = sum of squares
+            const float fy = gy - (float)cy, fz = gz - (float)cz;
+            const float gym = fmaxf(fy, 0.0f) * h, gyp = fmaxf(1.0f - fy, 0.0f) * h;
+            const float gzm = fmaxf(fz, 0.0f) * h, gzp = fmaxf(1.0f - fz, 0.0f) * h;
+            const bool ym = cy > 0, yp = cy < ny - 1, zm = cz > 0, zp = cz < nz - 1;
+            auto row_gap2 = [&](int k) -> float {
+                const int dy = (int)((OYP >> (2 * k)) & 3u) - 1, dz = (int)((OZP >> (2 * k)) & 3u) - 1;
+                const float ry = dy < 0 ? gym : (dy > 0 ? gyp : 0.0f);
+                const float rz = dz < 0 ? gzm : (dz > 0 ? gzp : 0.0f);
+                return (ry * ry + rz * rz) * 0.998f;
+            };
+            uint32_t mask = 0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int y = cy + oy[k], z = cz + oz[k];
-                const bool inside = y >= 0 && y < ny && z >= 0 && z < nz;
-                const float ry = cell_gap(gy, y, cy) * h, rz = cell_gap(gz, z, cz) * h;
-                gap2[k] = inside ? (ry * ry + rz * rz) * 0.998f : 3.0e38f;
-                ra[k] = 0;
-                rb[k] = 0;
-                if (gap2[k] < hit.d2) {
-                    const size_t row = ((size_t)z * ny + y) * nx;
-                    ra[k] = g.cell_start[row + x0];
-                    rb[k] = g.cell_start[row + x1 + 1];
-                }
+                const int dy = (int)((OYP >> (2 * k)) & 3u) - 1, dz = (int)((OZP >> (2 * k)) & 3u) - 1;
+                const bool inside = (dy < 0 ? ym : (dy > 0 ? yp : true)) && (dz < 0 ? zm : (dz > 0 ? zp : true));
+                if (inside && row_gap2(k) < hit.d2) mask |= 1u << k;
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (gap2[k] < hit.d2) scan_range<WINDOW>(g, w, ra[k], rb[k], qx, qy, qz, hit);
+            uint32_t a = 0, b = 0;
+            int k = -1;
+            if (mask) {
+                k = __ffs((int)mask) - 1;
+                mask &= mask - 1;
+                const int dy = (int)((OYP >> (2 * k)) & 3u) - 1, dz = (int)((OZP >> (2 * k)) & 3u) - 1;
+                const size_t row = ((size_t)(cz + dz) * ny + (cy + dy)) * nx;
+                a = g.cell_start[row + x0];
+                b = g.cell_start[row + x1 + 1];
+            }
+            while (k >= 0) {
+                uint32_t a1 = 0, b1 = 0;
+                int k1 = -1;
+                if (mask) { // request the next row's bounds before scanning this one
+                    k1 = __ffs((int)mask) - 1;
+                    mask &= mask - 1;
+                    const int dy = (int)((OYP >> (2 * k1)) & 3u) - 1, dz = (int)((OZP >> (2 * k1)) & 3u) - 1;
+                    const size_t row = ((size_t)(cz + dz) * ny + (cy + dy)) * nx;
+                    a1 = g.cell_start[row + x0];
+                    b1 = g.cell_start[row + x1 + 1];
+                }
+                if (row_gap2(k) < hit.d2) scan_range<WINDOW>(g, w, a, b, qx, qy, qz, hit);
+                k = k1;
+                a = a1;
+                b = b1;
+            }
         } else {
             const int y0 = max(cy - R, 0), y1 = min(cy + R, ny - 1);
             const int z0 = max(cz - R, 0), z1 = min(cz + R, nz - 1);
