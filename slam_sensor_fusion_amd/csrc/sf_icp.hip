@@ -248,23 +248,105 @@ __device__ __forceinline__ void vec6_to_mat4(const double (&v)[6], double (&T)[1
 }
 
 // ------------------------------------------------------------------ reductions
+// Wave-level sum of 32 doubles per lane in ~125 VALU instructions and no LDS traffic
+// (a plain xor-shuffle reduction of 30 doubles costs 360 ds_bpermute + 180 adds per wave and
+// dominated the kernel's instruction issue — profiles/).  Transposing butterfly: at every
+// step each lane keeps HALF of its values and adds its partner's copy of that half, so the
+// number of live values halves while the number of lanes summed doubles:
+//   32 -> 16  partner l ^ 32   v_permlane32_swap   (gfx950)
+//   16 ->  8  partner l ^ 16   v_permlane16_swap   (gfx950)
+//    8 ->  4  partner l ^ 8    DPP row_ror:8
+//    4 ->  2  partner 7-(l&7)  DPP row_half_mirror
+//    2 ->  1  partner l ^ 2    DPP quad_perm [2,3,0,1]
+//    final    partner l ^ 1    DPP quad_perm [1,0,3,2]
+// Afterwards lane l holds the 64-lane total of component (l >> 1).  Fixed order => bitwise
+// reproducible.
+__device__ __forceinline__ double swap_add_32(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+__device__ __forceinline__ double swap_add_16(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+template <int DPP_CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)__double2loint(v), DPP_CTRL, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)__double2hiint(v), DPP_CTRL, 0xf, 0xf, false);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+template <int DPP_CTRL>
+__device__ __forceinline__ double dpp_keep_add(double a, double b, bool upper)
+{
+    const double keep = upper ? b : a, give = upper ? a : b;
+    return keep + dpp_f64<DPP_CTRL>(give);
+}
+
+__device__ __forceinline__ double wave_reduce_32(double (&v)[32])
+{
+    const int lane = threadIdx.x & 63;
+    double w16[16], w8[8], w4[4], w2[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w16[i] = swap_add_32(v[i], v[i + 16]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w8[i] = swap_add_16(w16[i], w16[i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w4[i] = dpp_keep_add<0x128>(w8[i], w8[i + 4], (lane & 8) != 0);   // row_ror:8
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w2[i] = dpp_keep_add<0x141>(w4[i], w4[i + 2], (lane & 4) != 0);   // row_half_mirror
+    const double w1 = dpp_keep_add<0x4e>(w2[0], w2[1], (lane & 2) != 0);                          // quad_perm [2,3,0,1]
+    return w1 + dpp_f64<0xb1>(w1);                                                                // quad_perm [1,0,3,2]
+}
+
+// 16-value form of the same butterfly (half the live registers): afterwards lane l holds the
+// 64-lane total of component (l >> 2) & 15.
+__device__ __forceinline__ double wave_reduce_16(double (&v)[16])
+{
+    const int lane = threadIdx.x & 63;
+    double w8[8], w4[4], w2[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w8[i] = swap_add_32(v[i], v[i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w4[i] = swap_add_16(w8[i], w8[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w2[i] = dpp_keep_add<0x128>(w4[i], w4[i + 2], (lane & 8) != 0);   // row_ror:8
+    double z = dpp_keep_add<0x141>(w2[0], w2[1], (lane & 4) != 0);                                // row_half_mirror
+    z = z + dpp_f64<0x4e>(z);                                                                     // quad_perm [2,3,0,1]
+    return z + dpp_f64<0xb1>(z);                                                                  // quad_perm [1,0,3,2]
+}
+
+// every lane gets the 64-lane total of one value
+__device__ __forceinline__ double wave_reduce_1(double v)
+{
+    v = swap_add_32(v, v);
+    v = swap_add_16(v, v);
+    v = v + dpp_f64<0x128>(v);
+    v = v + dpp_f64<0x141>(v);
+    v = v + dpp_f64<0x4e>(v);
+    return v + dpp_f64<0xb1>(v);
+}
+
 // Slab layout: partials[(scan * nblocks + block) * 32 + component] — a workgroup's record
 // is one contiguous 256-byte row, so both the store here and the column sums below are
 // coalesced.
 template <int NREC>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NREC], double *__restrict__ dst)
 {
+    double v[32];
 #pragma unroll
-    for (int c = 0; c < NREC; ++c) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc[c] += __shfl_xor(acc[c], off);
-    }
-    __shared__ double s[BLK / 64][NREC];
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int c = 0; c < NREC; ++c) s[w][c] = acc[c];
-    }
+    for (int c = 0; c < 32; ++c) v[c] = c < NREC ? acc[c] : 0.0;
+    const double total = wave_reduce_32(v);
+    __shared__ double s[BLK / 64][32];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((lane & 1) == 0) s[w][lane >> 1] = total;
     __syncthreads();
     if (threadIdx.x < NREC) {
         const int c = threadIdx.x;
@@ -333,7 +415,7 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
 // runs first with nothing else live in registers; the pair's contribution is formed
 // afterwards and goes straight into the wave reduction.
 template <int MODE, bool WINDOW, bool SHARD>
-__global__ __launch_bounds__(BLK) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
+__global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                                 int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
@@ -353,40 +435,89 @@ __global__ __launch_bounds__(BLK) void k_nn_red(SfGrid g, SfWindow w, const floa
         const float qx = (float)sx, qy = (float)sy, qz = (float)sz;
         if (!SHARD || (qx >= xlo && qx < xhi)) hit = sf::nn_search<WINDOW>(g, w, qx, qy, qz, thr);
     }
-    double acc[NREC];
+    // contribution of this lane's pair, reduced over the wave in two halves of 16 values
+    // (keeps the live registers low enough for 4+ waves per SIMD), staged per wave in LDS
+    __shared__ double stage[BLK / 64][32];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool ok = hit.j >= 0;
+    const double tx = hit.px, ty = hit.py, tz = hit.pz;
+    const double ex = sx - tx, ey = sy - ty, ez = sz - tz;
+    const double d2 = ex * ex + ey * ey + ez * ez;
+    if (MODE == 1) {
+        double v[16];
+        v[0] = 1.0;
+        v[1] = sx; v[2] = sy; v[3] = sz;
+        v[4] = tx; v[5] = ty; v[6] = tz;
+        v[7] = sx * tx; v[8] = sx * ty; v[9] = sx * tz;
+        v[10] = sy * tx; v[11] = sy * ty; v[12] = sy * tz;
+        v[13] = sz * tx; v[14] = sz * ty; v[15] = sz * tz;
 #pragma unroll
-    for (int c = 0; c < NREC; ++c) acc[c] = 0.0;
-    if (hit.j >= 0) {
-        const double tx = hit.p.x, ty = hit.p.y, tz = hit.p.z;
-        const double ex = sx - tx, ey = sy - ty, ez = sz - tz;
-        const double d2 = ex * ex + ey * ey + ez * ez;
-        if (MODE == 1) {
-            acc[0] = 1.0;
-            acc[1] = sx; acc[2] = sy; acc[3] = sz;
-            acc[4] = tx; acc[5] = ty; acc[6] = tz;
-            acc[7] = sx * tx; acc[8] = sx * ty; acc[9] = sx * tz;
-            acc[10] = sy * tx; acc[11] = sy * ty; acc[12] = sy * tz;
-            acc[13] = sz * tx; acc[14] = sz * ty; acc[15] = sz * tz;
-            acc[16] = d2;
-        } else {
-            const float4 nf = g.nrm[hit.j];
-            const double nx = nf.x, ny = nf.y, nz = nf.z;
-            const double r = ex * nx + ey * ny + ez * nz;
-            const double J[6] = {sy * nz - sz * ny, sz * nx - sx * nz, sx * ny - sy * nx, nx, ny, nz};
-            acc[0] = 1.0;
-            acc[1] = r * r;
+        for (int c = 0; c < 16; ++c) v[c] = ok ? v[c] : 0.0;
+        const double t0 = wave_reduce_16(v);
+        const double t1 = wave_reduce_1(ok ? d2 : 0.0);
+        if ((lane & 3) == 0) stage[wv][lane >> 2] = t0;
+        if (lane == 0) stage[wv][16] = t1;
+    } else {
+        float nfx = 0.0f, nfy = 0.0f, nfz = 1.0f;
+        if (ok) {
+            // the winner's normal: from the bucket line it was found in, or the sorted normal array
+            if (hit.bcell >= 0) {
+                const float *bf = reinterpret_cast<const float *>(g.bkt + (size_t)hit.bcell * SF_BKT_F4);
+                nfx = bf[16 + hit.bslot]; nfy = bf[20 + hit.bslot]; nfz = bf[24 + hit.bslot];
+            } else {
+                const float4 nf = g.nrm[hit.j];
+                nfx = nf.x; nfy = nf.y; nfz = nf.z;
+            }
+        }
+        const double nx = nfx, ny = nfy, nz = nfz;
+        const double r = ex * nx + ey * ny + ez * nz;
+        const double J[6] = {sy * nz - sz * ny, sz * nx - sx * nz, sx * ny - sy * nx, nx, ny, nz};
+        {   // record[0..15] = n, sum r^2, JtJ (0,0) (0,1) .. (0,5) (1,1) .. (1,5) (2,2) (2,3) (2,4)
+            double v[16];
+            v[0] = 1.0;
+            v[1] = r * r;
             int k = 2;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
 #pragma unroll
-                for (int c = a; c < 6; ++c) { acc[k] = J[a] * J[c]; ++k; }
+                for (int c = a; c < 6; ++c) {
+                    if (k < 16) v[k] = J[a] * J[c];
+                    ++k;
+                }
             }
 #pragma unroll
-            for (int a = 0; a < 6; ++a) acc[23 + a] = J[a] * r;
-            acc[29] = d2;
+            for (int c = 0; c < 16; ++c) v[c] = ok ? v[c] : 0.0;
+            const double t0 = wave_reduce_16(v);
+            if ((lane & 3) == 0) stage[wv][lane >> 2] = t0;
+        }
+        {   // record[16..31] = JtJ (2,5) (3,3) .. (5,5), Jtr[6], sum d2, 0, 0
+            double v[16];
+            int k = 2;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int c = a; c < 6; ++c) {
+                    if (k >= 16) v[k - 16] = J[a] * J[c];
+                    ++k;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) v[7 + a] = J[a] * r;
+            v[13] = d2;
+            v[14] = 0.0;
+            v[15] = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = ok ? v[c] : 0.0;
+            const double t1 = wave_reduce_16(v);
+            if ((lane & 3) == 0) stage[wv][16 + (lane >> 2)] = t1;
         }
     }
-    block_reduce_store<NREC>(acc, partials + ((size_t)b * nblocks + blockIdx.x) * REC_STRIDE);
+    __syncthreads();
+    if (threadIdx.x < NREC) {
+        const int c = threadIdx.x;
+        double *dst = partials + ((size_t)b * nblocks + blockIdx.x) * REC_STRIDE;
+        dst[c] = ((stage[0][c] + stage[1][c]) + stage[2][c]) + stage[3][c];
+    }
 }
 
 // ------------------------------------------------------------------ solves (thread 0 of the scan's workgroup)

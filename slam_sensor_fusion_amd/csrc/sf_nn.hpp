@@ -3,13 +3,23 @@
 // Replaces the N serial FLANN kd-tree descents of
 // localization/src/icp_point_to_point.cpp:64-69 (sourceTargetCorrespondences) and the
 // Open3D hybrid search behind localization_python/.../localization_node.py:233-237.
-// One lane per query.  The map is sorted by cell (x fastest), so the 2R+1 cells of one
-// (y,z) row are ONE contiguous candidate range: a (2R+1)^3 block costs (2R+1)^2 range
-// look-ups, each followed by 16-byte candidate loads (x, y, z, original index).
-// The path is latency-bound (random 16-byte gathers served by L2 / Infinity Cache), so
-// the code is written for memory-level parallelism: the centre row first (it usually
-// holds the answer and prunes the rest), then the range bounds of all surviving rows in
-// one batch of independent loads, candidates fetched four at a time.
+// One lane per query.
+//
+// Measured on MI355X (profiles/): this path is bound by the RATE OF MEMORY REQUESTS that
+// leave the CU (random gathers over a working set far larger than the 4 MiB per-XCD L2:
+// L2 hit rate 16 %, ~56 G requests/s chip-wide at saturation), not by HBM bandwidth and not
+// by instruction issue.  So the layout is chosen to minimise cache lines per query:
+//
+//   ring 1, bucket path (SfGrid.bkt): every grid cell owns one 128-byte line holding up to
+//     4 points (SoA inside the line) + their normals: visiting a cell is ONE request with no
+//     cell_start indirection.  The query's own cell first, then only those of the 26
+//     neighbours whose gap to the query is smaller than the best distance so far — the
+//     neighbour list is per-LANE data (a bit mask walked with ffs), and the next cell's line
+//     is requested before the current one is evaluated.
+//   CSR path (cells with > 4 points, rings >= 2, maps without buckets): the map is sorted by
+//     cell (x fastest), so the 2R+1 cells of one (y,z) row are one contiguous candidate
+//     range [cell_start[row+x0], cell_start[row+x1+1]); candidates fetched four at a time.
+//
 // Exactness: after scanning the block of radius R around the query's cell, every
 // unscanned point is at least m = distance(query, block boundary) away; the search stops
 // when best <= m^2 (best starts at the acceptance threshold, so "nothing acceptable
@@ -23,7 +33,9 @@ namespace sf {
 struct NNHit {
     float d2;      // squared distance of the best candidate (== threshold if none)
     int j;         // sorted position of the best candidate, -1 if none
-    float4 p;      // its x, y, z, bitcast(original index)
+    float px, py, pz; // its coordinates
+    int bcell;     // bucket (cell id) the winner was read from, -1 if it came through the CSR path
+    int bslot;     // slot inside that bucket
 };
 
 __device__ __forceinline__ float l2_simple(float qx, float qy, float qz, float px, float py, float pz)
@@ -52,32 +64,79 @@ __device__ __forceinline__ bool window_accepts(const SfWindow &w, float px, floa
 }
 
 template <bool WINDOW>
-__device__ __forceinline__ void consider(const SfWindow &w, const float4 &p, uint32_t j, bool valid, float qx, float qy, float qz, NNHit &hit)
+__device__ __forceinline__ void consider(const SfWindow &w, float px, float py, float pz, int j, int bcell, int bslot, bool valid, float qx, float qy, float qz,
+                                         NNHit &hit)
 {
-    const float d2 = l2_simple(qx, qy, qz, p.x, p.y, p.z);
+    const float d2 = l2_simple(qx, qy, qz, px, py, pz);
     if (valid && d2 < hit.d2) {
-        if (!WINDOW || window_accepts(w, p.x, p.y, p.z)) {
+        if (!WINDOW || window_accepts(w, px, py, pz)) {
             hit.d2 = d2;
-            hit.j = (int)j;
-            hit.p = p;
+            hit.j = j;
+            hit.px = px; hit.py = py; hit.pz = pz;
+            hit.bcell = bcell;
+            hit.bslot = bslot;
         }
     }
 }
 
-// candidates [a, b), four independent 16-byte loads in flight per step (indices clamped
-// into the range, the tail is masked)
+// CSR candidates [a, b), four independent 16-byte loads in flight per step
 template <bool WINDOW>
 __device__ __forceinline__ void scan_range(const SfGrid &g, const SfWindow &w, uint32_t a, uint32_t b, float qx, float qy, float qz, NNHit &hit)
 {
     for (uint32_t j = a; j < b; j += 4) {
+        // all four loads are issued unconditionally (indices clamped into the range) so they are
+        // in flight together: a predicated load per candidate costs a round trip each (measured)
         const uint32_t last = b - 1;
         const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
         const float4 p0 = g.pts[j], p1 = g.pts[j1], p2 = g.pts[j2], p3 = g.pts[j3];
-        consider<WINDOW>(w, p0, j, true, qx, qy, qz, hit);
-        consider<WINDOW>(w, p1, j1, j + 1 < b, qx, qy, qz, hit);
-        consider<WINDOW>(w, p2, j2, j + 2 < b, qx, qy, qz, hit);
-        consider<WINDOW>(w, p3, j3, j + 3 < b, qx, qy, qz, hit);
+        consider<WINDOW>(w, p0.x, p0.y, p0.z, (int)j, -1, 0, true, qx, qy, qz, hit);
+        consider<WINDOW>(w, p1.x, p1.y, p1.z, (int)j1, -1, 0, j + 1 < b, qx, qy, qz, hit);
+        consider<WINDOW>(w, p2.x, p2.y, p2.z, (int)j2, -1, 0, j + 2 < b, qx, qy, qz, hit);
+        consider<WINDOW>(w, p3.x, p3.y, p3.z, (int)j3, -1, 0, j + 3 < b, qx, qy, qz, hit);
     }
+}
+
+// cell_start[c-1 .. c+2] in ONE 16-byte load (the table carries one pad entry in front, so
+// c - 1 >= -1 is addressable; dword alignment is enough for global_load_dwordx4)
+struct __attribute__((packed, aligned(4))) RowBounds { uint32_t s0, s1, s2, s3; };
+__device__ __forceinline__ RowBounds load_row_bounds(const SfGrid &g, size_t cell)
+{
+    return *reinterpret_cast<const RowBounds *>(g.cell_start + cell - 1);
+}
+
+// one (y,z) row around column cx: the query's own x cell first, then the left / right cell
+// only while their gap (row gap + x gap) is still smaller than the best distance
+template <bool WINDOW>
+__device__ __forceinline__ void scan_row(const SfGrid &g, const SfWindow &w, const RowBounds &rb, float gap2yz, float gxm2, float gxp2, bool xm, bool xp, float qx,
+                                         float qy, float qz, NNHit &hit)
+{
+    scan_range<WINDOW>(g, w, rb.s1, rb.s2, qx, qy, qz, hit);
+    if (xm && (gap2yz + gxm2) * 0.998f < hit.d2) scan_range<WINDOW>(g, w, rb.s0, rb.s1, qx, qy, qz, hit);
+    if (xp && (gap2yz + gxp2) * 0.998f < hit.d2) scan_range<WINDOW>(g, w, rb.s2, rb.s3, qx, qy, qz, hit);
+}
+
+struct Bucket { float4 x, y, z, j; };
+
+__device__ __forceinline__ Bucket load_bucket(const SfGrid &g, int cell)
+{
+    const float4 *b = g.bkt + (size_t)cell * SF_BKT_F4;
+    Bucket r;
+    r.x = b[0]; r.y = b[1]; r.z = b[2]; r.j = b[3];
+    return r;
+}
+
+template <bool WINDOW>
+__device__ __forceinline__ void scan_bucket(const SfGrid &g, const SfWindow &w, int cell, const Bucket &b, float qx, float qy, float qz, NNHit &hit)
+{
+    const int j0 = __float_as_int(b.j.x), j1 = __float_as_int(b.j.y), j2 = __float_as_int(b.j.z), j3 = __float_as_int(b.j.w);
+    if (j3 == -2) { // more than 4 points in this cell: CSR range of the single cell
+        scan_range<WINDOW>(g, w, g.cell_start[cell], g.cell_start[cell + 1], qx, qy, qz, hit);
+        return;
+    }
+    consider<WINDOW>(w, b.x.x, b.y.x, b.z.x, j0, cell, 0, j0 >= 0, qx, qy, qz, hit);
+    consider<WINDOW>(w, b.x.y, b.y.y, b.z.y, j1, cell, 1, j1 >= 0, qx, qy, qz, hit);
+    consider<WINDOW>(w, b.x.z, b.y.z, b.z.z, j2, cell, 2, j2 >= 0, qx, qy, qz, hit);
+    consider<WINDOW>(w, b.x.w, b.y.w, b.z.w, j3, cell, 3, j3 >= 0, qx, qy, qz, hit);
 }
 
 // distance (in cells, >= 0) from grid coordinate gc to the cell interval [c, c+1]
@@ -88,6 +147,13 @@ __device__ __forceinline__ float cell_gap(float gc, int c, int cq)
     return d > 0.0f ? d : 0.0f;
 }
 
+// the 26 neighbours of a cell: 6 faces, 12 edges, 8 corners; per-axis (offset + 1) packed
+// in 2-bit fields of one 64-bit constant each (no table in memory)
+constexpr unsigned long long NB_OXP = 0x8888558888558ull;
+constexpr unsigned long long NB_OYP = 0xa0a08855a0585ull;
+constexpr unsigned long long NB_OZP = 0xaa00a0a055855ull;
+__device__ __forceinline__ int nb_off(unsigned long long packed, int k) { return (int)((packed >> (2 * k)) & 3ull) - 1; }
+
 // thr: candidates are accepted iff d2 < thr (reference: max_correspondence_dist_ itself,
 // icp_point_to_point.cpp:70; Open3D: radius^2)
 template <bool WINDOW>
@@ -96,7 +162,9 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
     NNHit hit;
     hit.d2 = thr;
     hit.j = -1;
-    hit.p = make_float4(0.f, 0.f, 0.f, 0.f);
+    hit.px = hit.py = hit.pz = 0.0f;
+    hit.bcell = -1;
+    hit.bslot = 0;
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || g.n == 0) return hit;
     const float gx = (qx - g.org[0]) * g.inv_h, gy = (qy - g.org[1]) * g.inv_h, gz = (qz - g.org[2]) * g.inv_h;
     const int nx = g.dim[0], ny = g.dim[1], nz = g.dim[2];
@@ -108,80 +176,183 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
     const int rcap = max(nx, max(ny, nz));
 
     for (int R = 1; R <= rcap; ++R) {
-        const int x0 = max(cx - R, 0), x1 = min(cx + R, nx - 1);
-        if (R == 1) {
-            // centre row first: it usually holds the answer and prunes most other rows
+        if (R == 1 && g.bkt != nullptr) {
+            // ---- bucket path: own cell, then the needed ones of the 26 neighbours
+            const int c0 = (cz * ny + cy) * nx + cx;
             {
-                const size_t row = ((size_t)cz * ny + cy) * nx;
-                const uint32_t a = g.cell_start[row + x0], b = g.cell_start[row + x1 + 1];
-                scan_range<WINDOW>(g, w, a, b, qx, qy, qz, hit);
+                const Bucket b = load_bucket(g, c0);
+                scan_bucket<WINDOW>(g, w, c0, b, qx, qy, qz, hit);
             }
-            // The 8 neighbouring rows (faces first, then corners).  Which of them a query still
-            // needs depends on where it sits inside its cell, so the row is per-LANE data: every
-            // lane walks only its own needed rows (a bit mask), the wave iterates
-            // max-over-lanes(popcount) times instead of 8, and the range bounds of a lane's
-            // next row are requested before its current row is scanned.
-            // row k: dy = OY(k) - 1, dz = OZ(k) - 1 with 2-bit fields packed in constants
-            //   k      0   1   2   3   4   5   6   7
-            //   dy    -1  +1   0   0  -1  +1  -1  +1
-            //   dz     0   0  -1  +1  -1  -1  +1  +1
-            constexpr uint32_t OYP = 0u | (2u << 2) | (1u << 4) | (1u << 6) | (0u << 8) | (2u << 10) | (0u << 12) | (2u << 14);
-            constexpr uint32_t OZP = 1u | (1u << 2) | (0u << 4) | (2u << 6) | (0u << 8) | (0u << 10) | (2u << 12) | (2u << 14);
-            // gaps to the four neighbouring slabs (in metres, >= 0); corner gap = sum of squares
-            const float fy = gy - (float)cy, fz = gz - (float)cz;
+            // gaps (metres, >= 0) from the query to the neighbouring slabs on each axis
+            const float fx = gx - (float)cx, fy = gy - (float)cy, fz = gz - (float)cz;
+            const float gxm = fmaxf(fx, 0.0f) * h, gxp = fmaxf(1.0f - fx, 0.0f) * h;
             const float gym = fmaxf(fy, 0.0f) * h, gyp = fmaxf(1.0f - fy, 0.0f) * h;
             const float gzm = fmaxf(fz, 0.0f) * h, gzp = fmaxf(1.0f - fz, 0.0f) * h;
-            const bool ym = cy > 0, yp = cy < ny - 1, zm = cz > 0, zp = cz < nz - 1;
-            auto row_gap2 = [&](int k) -> float {
-                const int dy = (int)((OYP >> (2 * k)) & 3u) - 1, dz = (int)((OZP >> (2 * k)) & 3u) - 1;
+            auto cell_gap2 = [&](int k) -> float {
+                const int dx = nb_off(NB_OXP, k), dy = nb_off(NB_OYP, k), dz = nb_off(NB_OZP, k);
+                const float rx = dx < 0 ? gxm : (dx > 0 ? gxp : 0.0f);
                 const float ry = dy < 0 ? gym : (dy > 0 ? gyp : 0.0f);
                 const float rz = dz < 0 ? gzm : (dz > 0 ? gzp : 0.0f);
-                return (ry * ry + rz * rz) * 0.998f;
+                return (rx * rx + ry * ry + rz * rz) * 0.998f;
+            };
+            auto cell_id = [&](int k) -> int {
+                return ((cz + nb_off(NB_OZP, k)) * ny + (cy + nb_off(NB_OYP, k))) * nx + (cx + nb_off(NB_OXP, k));
             };
             uint32_t mask = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int dy = (int)((OYP >> (2 * k)) & 3u) - 1, dz = (int)((OZP >> (2 * k)) & 3u) - 1;
-                const bool inside = (dy < 0 ? ym : (dy > 0 ? yp : true)) && (dz < 0 ? zm : (dz > 0 ? zp : true));
-                if (inside && row_gap2(k) < hit.d2) mask |= 1u << k;
+            for (int k = 0; k < 26; ++k) {
+                const int dx = nb_off(NB_OXP, k), dy = nb_off(NB_OYP, k), dz = nb_off(NB_OZP, k);
+                const bool inside = (unsigned)(cx + dx) < (unsigned)nx && (unsigned)(cy + dy) < (unsigned)ny && (unsigned)(cz + dz) < (unsigned)nz;
+                if (inside && cell_gap2(k) < hit.d2) mask |= 1u << k;
             }
-            uint32_t a = 0, b = 0;
-            int k = -1;
+            int k = -1, cell = 0;
+            Bucket cur;
+            cur.x = cur.y = cur.z = cur.j = make_float4(0.f, 0.f, 0.f, 0.f);
             if (mask) {
                 k = __ffs((int)mask) - 1;
                 mask &= mask - 1;
-                const int dy = (int)((OYP >> (2 * k)) & 3u) - 1, dz = (int)((OZP >> (2 * k)) & 3u) - 1;
-                const size_t row = ((size_t)(cz + dz) * ny + (cy + dy)) * nx;
-                a = g.cell_start[row + x0];
-                b = g.cell_start[row + x1 + 1];
+                cell = cell_id(k);
+                cur = load_bucket(g, cell);
             }
             while (k >= 0) {
-                uint32_t a1 = 0, b1 = 0;
-                int k1 = -1;
-                if (mask) { // request the next row's bounds before scanning this one
-                    k1 = __ffs((int)mask) - 1;
+                int k1 = -1, cell1 = 0;
+                Bucket nxt = cur;
+                while (mask) { // next still-needed neighbour: request its line before evaluating this one
+                    const int kk = __ffs((int)mask) - 1;
                     mask &= mask - 1;
-                    const int dy = (int)((OYP >> (2 * k1)) & 3u) - 1, dz = (int)((OZP >> (2 * k1)) & 3u) - 1;
-                    const size_t row = ((size_t)(cz + dz) * ny + (cy + dy)) * nx;
-                    a1 = g.cell_start[row + x0];
-                    b1 = g.cell_start[row + x1 + 1];
+                    if (cell_gap2(kk) < hit.d2) {
+                        k1 = kk;
+                        cell1 = cell_id(kk);
+                        nxt = load_bucket(g, cell1);
+                        break;
+                    }
                 }
-                if (row_gap2(k) < hit.d2) scan_range<WINDOW>(g, w, a, b, qx, qy, qz, hit);
+                if (cell_gap2(k) < hit.d2) scan_bucket<WINDOW>(g, w, cell, cur, qx, qy, qz, hit);
                 k = k1;
-                a = a1;
-                b = b1;
+                cell = cell1;
+                cur = nxt;
             }
         } else {
+            // ---- CSR path: rows of 2R+1 cells
+            const int x0 = max(cx - R, 0), x1 = min(cx + R, nx - 1);
             const int y0 = max(cy - R, 0), y1 = min(cy + R, ny - 1);
             const int z0 = max(cz - R, 0), z1 = min(cz + R, nz - 1);
-            for (int z = z0; z <= z1; ++z) {
-                const float rz = cell_gap(gz, z, cz) * h;
-                for (int y = y0; y <= y1; ++y) {
-                    const float ry = cell_gap(gy, y, cy) * h;
-                    if ((ry * ry + rz * rz) * 0.998f >= hit.d2) continue;
-                    const size_t row = ((size_t)z * ny + y) * nx;
-                    const uint32_t a = g.cell_start[row + x0], b = g.cell_start[row + x1 + 1];
-                    scan_range<WINDOW>(g, w, a, b, qx, qy, qz, hit);
+#ifndef SF_NN_R1
+#define SF_NN_R1 2
+#endif
+#if SF_NN_R1 == 0
+            if (R == 1) { // simplest: centre row, then the 8 others in a uniform loop
+                const size_t row0 = ((size_t)cz * ny + cy) * nx;
+                scan_range<WINDOW>(g, w, g.cell_start[row0 + x0], g.cell_start[row0 + x1 + 1], qx, qy, qz, hit);
+                for (int z = z0; z <= z1; ++z) {
+                    const float rz = cell_gap(gz, z, cz) * h;
+                    for (int y = y0; y <= y1; ++y) {
+                        if (y == cy && z == cz) continue;
+                        const float ry = cell_gap(gy, y, cy) * h;
+                        if ((ry * ry + rz * rz) * 0.998f >= hit.d2) continue;
+                        const size_t row = ((size_t)z * ny + y) * nx;
+                        scan_range<WINDOW>(g, w, g.cell_start[row + x0], g.cell_start[row + x1 + 1], qx, qy, qz, hit);
+                    }
+                }
+#elif SF_NN_R1 == 1
+            if (R == 1) { // centre row, then the bounds of every surviving row in one batch
+                const size_t row0 = ((size_t)cz * ny + cy) * nx;
+                scan_range<WINDOW>(g, w, g.cell_start[row0 + x0], g.cell_start[row0 + x1 + 1], qx, qy, qz, hit);
+                const int oy[8] = {-1, 1, 0, 0, -1, 1, -1, 1};
+                const int oz[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+                uint32_t ra[8], rb[8];
+                float gap2[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int y = cy + oy[k], z = cz + oz[k];
+                    const bool inside = y >= 0 && y < ny && z >= 0 && z < nz;
+                    const float ry = cell_gap(gy, y, cy) * h, rz = cell_gap(gz, z, cz) * h;
+                    gap2[k] = inside ? (ry * ry + rz * rz) * 0.998f : 3.0e38f;
+                    ra[k] = 0;
+                    rb[k] = 0;
+                    if (gap2[k] < hit.d2) {
+                        const size_t row = ((size_t)z * ny + y) * nx;
+                        ra[k] = g.cell_start[row + x0];
+                        rb[k] = g.cell_start[row + x1 + 1];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (gap2[k] < hit.d2) scan_range<WINDOW>(g, w, ra[k], rb[k], qx, qy, qz, hit);
+#else
+            if (R == 1) {
+                // Ring 1 on the CSR rows.  Per query: one 16-byte look-up gives the bounds of the
+                // three cells of a row; the own cell is scanned first, the x neighbours and the
+                // 8 neighbouring rows only while their gap is smaller than the best distance.
+                // Which rows a query needs depends on where it sits in its cell, so the row list is
+                // per-LANE data (bit mask walked with ffs) and the next row's bounds are requested
+                // before the current row is scanned.
+                //   k      0   1   2   3   4   5   6   7
+                //   dy    -1  +1   0   0  -1  +1  -1  +1
+                //   dz     0   0  -1  +1  -1  -1  +1  +1
+                constexpr uint32_t OYP = 0u | (2u << 2) | (1u << 4) | (1u << 6) | (0u << 8) | (2u << 10) | (0u << 12) | (2u << 14);
+                constexpr uint32_t OZP = 1u | (1u << 2) | (0u << 4) | (2u << 6) | (0u << 8) | (0u << 10) | (2u << 12) | (2u << 14);
+                const float fx = gx - (float)cx, fy = gy - (float)cy, fz = gz - (float)cz;
+                const float gxm = fmaxf(fx, 0.0f) * h, gxp = fmaxf(1.0f - fx, 0.0f) * h;
+                const float gym = fmaxf(fy, 0.0f) * h, gyp = fmaxf(1.0f - fy, 0.0f) * h;
+                const float gzm = fmaxf(fz, 0.0f) * h, gzp = fmaxf(1.0f - fz, 0.0f) * h;
+                const float gxm2 = gxm * gxm, gxp2 = gxp * gxp;
+                const bool xm = cx > 0, xp = cx < nx - 1;
+                auto row_gap2 = [&](int k) -> float {
+                    const int dy = (int)((OYP >> (2 * k)) & 3u) - 1, dz = (int)((OZP >> (2 * k)) & 3u) - 1;
+                    const float ry = dy < 0 ? gym : (dy > 0 ? gyp : 0.0f);
+                    const float rz = dz < 0 ? gzm : (dz > 0 ? gzp : 0.0f);
+                    return ry * ry + rz * rz;
+                };
+                auto row_cell = [&](int k) -> size_t {
+                    const int dy = (int)((OYP >> (2 * k)) & 3u) - 1, dz = (int)((OZP >> (2 * k)) & 3u) - 1;
+                    return ((size_t)(cz + dz) * ny + (cy + dy)) * nx + cx;
+                };
+                {
+                    const RowBounds rb = load_row_bounds(g, ((size_t)cz * ny + cy) * nx + cx);
+                    scan_row<WINDOW>(g, w, rb, 0.0f, gxm2, gxp2, xm, xp, qx, qy, qz, hit);
+                }
+                uint32_t mask = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int dy = (int)((OYP >> (2 * k)) & 3u) - 1, dz = (int)((OZP >> (2 * k)) & 3u) - 1;
+                    const bool inside = (unsigned)(cy + dy) < (unsigned)ny && (unsigned)(cz + dz) < (unsigned)nz;
+                    if (inside && row_gap2(k) * 0.998f < hit.d2) mask |= 1u << k;
+                }
+                int k = -1;
+                RowBounds cur = {0, 0, 0, 0};
+                if (mask) {
+                    k = __ffs((int)mask) - 1;
+                    mask &= mask - 1;
+                    cur = load_row_bounds(g, row_cell(k));
+                }
+                while (k >= 0) {
+                    int k1 = -1;
+                    RowBounds nxt = cur;
+                    while (mask) {
+                        const int kk = __ffs((int)mask) - 1;
+                        mask &= mask - 1;
+                        if (row_gap2(kk) * 0.998f < hit.d2) {
+                            k1 = kk;
+                            nxt = load_row_bounds(g, row_cell(kk));
+                            break;
+                        }
+                    }
+                    const float g2 = row_gap2(k);
+                    if (g2 * 0.998f < hit.d2) scan_row<WINDOW>(g, w, cur, g2, gxm2, gxp2, xm, xp, qx, qy, qz, hit);
+                    k = k1;
+                    cur = nxt;
+                }
+#endif
+            } else {
+                for (int z = z0; z <= z1; ++z) {
+                    const float rz = cell_gap(gz, z, cz) * h;
+                    for (int y = y0; y <= y1; ++y) {
+                        const float ry = cell_gap(gy, y, cy) * h;
+                        if ((ry * ry + rz * rz) * 0.998f >= hit.d2) continue;
+                        const size_t row = ((size_t)z * ny + y) * nx;
+                        scan_range<WINDOW>(g, w, g.cell_start[row + x0], g.cell_start[row + x1 + 1], qx, qy, qz, hit);
+                    }
                 }
             }
         }
