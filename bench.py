@@ -40,12 +40,14 @@ def parse():
     ap.add_argument("--map-points", type=int, default=10_000_000)
     ap.add_argument("--scan-points", type=int, default=200_000)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=8, help="scans registered concurrently per step")
+    ap.add_argument("--batch", type=int, default=32, help="scans registered concurrently per step")
     ap.add_argument("--mode", default="p2plane", choices=["p2plane", "o3d_p2p"])
     ap.add_argument("--cell", type=float, default=0.25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=20)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, default); gloo only to rehearse the N>1 path with several ranks on ONE GPU")
     return ap.parse_args()
 
 
@@ -59,13 +61,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); torch.cuda.is_available() is False")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
     stream = torch.cuda.Stream()
-    ctx = api.Context(local_rank, stream.cuda_stream)
+    ctx = api.Context(device, stream.cuda_stream)
 
     # ---------------- setup (untimed): map build on the device, scans resident in HBM
     t_setup = time.time()
@@ -151,6 +157,19 @@ def main():
     queries_per_launch = n_scan * B / (world if world > 1 else 1)
     achieved_gbs = queries_per_launch * a_nn / (nn_ms * 1e-3) / 1e9 if nn_ms > 0 else 0.0
 
+    # ---------------- single-scan latency (one scan in flight, graph replay), outside the timed region
+    single_ms = None
+    if world == 1:
+        lat = api.Icp(ctx, max_dist, args.iters, 0.05, 1e-5)
+        lat.set_target(mp)
+        lat.set_source(scans[0])
+        lat.use_graph(not args.no_graph)
+        lat.align(args.mode)
+        tl = time.perf_counter()
+        for _ in range(10):
+            lat.align(args.mode)
+        single_ms = (time.perf_counter() - tl) / 10 * 1e3
+
     scans_total = B * args.steps
     value = scans_total / elapsed
     ms_per_step = elapsed / args.steps * 1e3
@@ -165,6 +184,7 @@ def main():
         "ms_per_step": ms_per_step,
         "ms_per_icp_iter": ms_per_step / nn_per_scan / B,
         "ms_per_icp_iter_batch": ms_per_step / nn_per_scan,
+        "single_scan_latency_ms": single_ms,
         "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None,
