@@ -207,6 +207,34 @@ int sf_icp_step_end(sf_icp *icp, int mode, int last);
 int sf_icp_profile_enable(sf_icp *icp, int on);
 int sf_icp_profile_read(sf_icp *icp, int64_t *nn_launches, double *nn_ms_total);
 
+/* ------------------------------------------------------------------ BruteForceAlignment (start-up coarse lock) */
+/* localization/include/localization/brute_force_alignment.h:22-112 and
+ * localization/src/brute_force_alignment.cpp: every candidate pose of the x,y,z,yaw grid is
+ * scored by the mean SQUARED NN distance of the source points (all candidates of one x slice
+ * in one launch); the first candidate under the threshold, in the reference's nesting
+ * order, wins.  Same setters, same state (previous / best transformation, first-alignment
+ * flag, the trace == 4 rule of setInitialGuess). */
+typedef struct sf_bf sf_bf;
+int sf_bf_create(sf_ctx *ctx, sf_bf **out);
+void sf_bf_destroy(sf_bf *bf);
+int sf_bf_set_xyz_step(sf_bf *bf, float x_step, float y_step, float z_step);
+int sf_bf_set_xyz_range(sf_bf *bf, float x, float y, float z);
+int sf_bf_set_rotation_step(sf_bf *bf, float yaw_step);
+int sf_bf_set_rotation_range(sf_bf *bf, float yaw);
+int sf_bf_set_mean_error_threshold(sf_bf *bf, float error_threshold);
+int sf_bf_set_initial_guess(sf_bf *bf, const float T[16]);
+int sf_bf_set_source(sf_bf *bf, const float *xyz, int64_t n);
+int sf_bf_set_source_cloud(sf_bf *bf, sf_cloud *cloud);
+int sf_bf_set_target(sf_bf *bf, const float *xyz, int64_t n);
+int sf_bf_set_target_map(sf_bf *bf, sf_map *map);
+int sf_bf_reset_first_alignment(sf_bf *bf, int value);
+int sf_bf_align_clouds(sf_bf *bf, int *found);
+int sf_bf_first_alignment_completed(sf_bf *bf);
+int sf_bf_get_best_transformation(sf_bf *bf, float T[16]);
+/* diagnostics of the last alignClouds: chosen candidate (nesting-order index), its score,
+ * and the float32 score of every candidate evaluated before the early exit (NaN after it) */
+int sf_bf_last_result(sf_bf *bf, int32_t *index, float *score, int32_t *n_candidates, float *scores, int64_t cap);
+
 /* ------------------------------------------------------------------ pose fusion (host, float32 like the reference) */
 /* a14: computePosePredictionFromOdometry — localization_node.cpp:89-110 */
 void sf_fusion_quat_to_pose(const double q_wxyz[4], const double t[3], float T[16]);

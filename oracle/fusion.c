@@ -327,3 +327,67 @@ int orc_bf_sequence(float range, float step, float *seq, int cap)
     }
     return k;
 }
+
+/* ------------------------------------------------------------------ BruteForceAlignment */
+/* brute_force_alignment.cpp:65-136: every candidate (x, y, z, yaw) in nesting order,
+ * T = previous * [Rz(yaw) | x y z] in float32, score = mean of the SQUARED NN distances
+ * (float32 sequential sum), first candidate under the threshold wins at once. */
+int orc_bf_align(const float *src, int n, const float *tgt, int m, float prev_T[16],
+                 const orc_bf_params *prm, float best_T[16], float *best_score, int *index,
+                 int *n_candidates, float *scores)
+{
+    float xs[512], ys[512], zs[512], ws[512];
+    const int nx = orc_bf_sequence(prm->x_range, prm->x_step, xs, 512);
+    const int ny = orc_bf_sequence(prm->y_range, prm->y_step, ys, 512);
+    const int nz = orc_bf_sequence(prm->z_range, prm->z_step, zs, 512);
+    const int nw = orc_bf_sequence(prm->yaw_range, prm->yaw_step, ws, 512);
+    if (n_candidates) *n_candidates = nx * ny * nz * nw;
+    orc_kdtree_f *tree = orc_kdtree_f_build(tgt, m, 15);
+    float bestT[16], bscore = 3.402823466e+38f;
+    for (int i = 0; i < 16; ++i) bestT[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    int bidx = -1, cand = 0, found = 0;
+    float *q = (float *)malloc(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1));
+    int *nn_i = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    float *nn_d = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    for (int a = 0; a < nx && !found; ++a)
+        for (int b = 0; b < ny && !found; ++b)
+            for (int c = 0; c < nz && !found; ++c)
+                for (int d = 0; d < nw && !found; ++d, ++cand) {
+                    const float yaw = ws[d];
+                    const float sn = sinf(yaw), cs = cosf(yaw), one_c = 1.0f - cs;
+                    const float L[16] = {0.0f + cs, 0.0f - sn, 0.0f, xs[a],
+                                         0.0f + sn, 0.0f + cs, 0.0f, ys[b],
+                                         0.0f, 0.0f, one_c * 1.0f + cs, zs[c],
+                                         0, 0, 0, 1};
+                    float T[16];
+                    orc_mat4f_mul(prev_T, L, T);
+                    for (int i = 0; i < n; ++i) { /* T * Vector4f(p, 1): column combination, k ascending */
+                        const float *p = src + 3 * (size_t)i;
+                        q[3 * (size_t)i + 0] = ((T[0] * p[0] + T[1] * p[1]) + T[2] * p[2]) + T[3] * 1.0f;
+                        q[3 * (size_t)i + 1] = ((T[4] * p[0] + T[5] * p[1]) + T[6] * p[2]) + T[7] * 1.0f;
+                        q[3 * (size_t)i + 2] = ((T[8] * p[0] + T[9] * p[1]) + T[10] * p[2]) + T[11] * 1.0f;
+                    }
+                    orc_kdtree_f_nn(tree, q, n, nn_i, nn_d);
+                    float score = 0.0f;
+                    for (int i = 0; i < n; ++i) score += nn_d[i];
+                    score /= (float)n;
+                    if (scores) scores[cand] = score;
+                    if (score < bscore) { bscore = score; memcpy(bestT, T, sizeof(bestT)); bidx = cand; }
+                    if (score < prm->threshold) {
+                        memcpy(best_T, T, sizeof(float) * 16);
+                        *best_score = score;
+                        *index = cand;
+                        found = 1;
+                    }
+                }
+    if (!found) {
+        memcpy(prev_T, bestT, sizeof(bestT)); /* :123 */
+        memcpy(best_T, bestT, sizeof(bestT));
+        *best_score = bscore;
+        *index = bidx;
+        found = bscore < prm->threshold; /* :126-131 (cannot be true here, kept for fidelity) */
+    }
+    orc_kdtree_f_free(tree);
+    free(q); free(nn_i); free(nn_d);
+    return found;
+}

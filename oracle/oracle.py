@@ -362,3 +362,23 @@ def bf_sequence(rng, step):
     seq = np.empty(4096, np.float32)
     k = lib().orc_bf_sequence(C.c_float(rng), C.c_float(step), _p(seq), C.c_int(4096))
     return seq[:k].copy()
+
+
+class BfParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("x_step", "y_step", "z_step", "yaw_step", "x_range", "y_range", "z_range",
+                                         "yaw_range", "threshold")]
+
+
+def bf_align(src, tgt, prev_T, x_step=0.1, y_step=0.1, z_step=0.05, yaw_step=np.pi / 18.0, x_range=1.5, y_range=1.5,
+             z_range=0.1, yaw_range=np.pi / 6.0, threshold=0.1):
+    """-> dict(found, best_T, best_score, index, n_candidates, scores, prev_T_after)"""
+    src, tgt = _f32(src).reshape(-1, 3), _f32(tgt).reshape(-1, 3)
+    prev = _f32(prev_T).reshape(16).copy()
+    prm = BfParams(x_step, y_step, z_step, yaw_step, x_range, y_range, z_range, yaw_range, threshold)
+    best = np.empty(16, np.float32)
+    score, idx, ncand = C.c_float(), C.c_int(), C.c_int()
+    scores = np.full(1 << 16, np.nan, np.float32)
+    found = lib().orc_bf_align(_p(src), C.c_int(len(src)), _p(tgt), C.c_int(len(tgt)), _p(prev), C.byref(prm), _p(best),
+                               C.byref(score), C.byref(idx), C.byref(ncand), _p(scores))
+    return dict(found=bool(found), best_T=best.reshape(4, 4), best_score=score.value, index=idx.value,
+                n_candidates=ncand.value, scores=scores[:ncand.value].copy(), prev_T_after=prev.reshape(4, 4))

@@ -169,6 +169,20 @@ void orc_sfilter_apply(const orc_sfilter *f, const float prev[16], const float c
  * cap values, returns count. */
 int orc_bf_sequence(float range, float step, float *seq, int cap);
 
+/* BruteForceAlignment::alignClouds — brute_force_alignment.cpp:65-136.  prev_T (row-major)
+ * is map_T_sensor_previous_ on entry and is updated like the reference on a miss (:123).
+ * Returns 1 when a candidate's mean squared NN distance fell below `threshold`.
+ * best_T: the transformation getBestTransformation() would return afterwards;
+ * index: position of the chosen candidate in x,y,z,yaw nesting order; scores (optional,
+ * n_candidates floats): the float32 score of every candidate that was evaluated (early
+ * exit leaves the rest untouched). */
+typedef struct {
+    float x_step, y_step, z_step, yaw_step, x_range, y_range, z_range, yaw_range, threshold;
+} orc_bf_params;
+int orc_bf_align(const float *src, int n, const float *tgt, int m, float prev_T[16],
+                 const orc_bf_params *prm, float best_T[16], float *best_score, int *index,
+                 int *n_candidates, float *scores);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,7 +45,7 @@ _live = weakref.WeakSet()   # every wrapper object, closed in dependency order a
 
 
 def _close_all():
-    for kind in ("Icp", "Map", "Cloud", "Context"):
+    for kind in ("Icp", "BruteForceAlignment", "Map", "Cloud", "Context"):
         for obj in [o for o in list(_live) if type(o).__name__ == kind]:
             try:
                 obj.close()
@@ -450,6 +450,85 @@ class Icp:
     def close(self):
         if self.h:
             self.lib.sf_icp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BruteForceAlignment:
+    """sf_bf: mirrors BruteForceAlignment (brute_force_alignment.h:22-112) setter for setter."""
+
+    def __init__(self, ctx):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.h = C.c_void_p()
+        self._map = None
+        _check(self.lib.sf_bf_create(ctx.h, C.byref(self.h)))
+        _live.add(self)
+
+    def setXYZStep(self, x, y, z):
+        _check(self.lib.sf_bf_set_xyz_step(self.h, C.c_float(x), C.c_float(y), C.c_float(z)))
+
+    def setXYZRange(self, x, y, z):
+        _check(self.lib.sf_bf_set_xyz_range(self.h, C.c_float(x), C.c_float(y), C.c_float(z)))
+
+    def setRotationStep(self, v):
+        _check(self.lib.sf_bf_set_rotation_step(self.h, C.c_float(v)))
+
+    def setRotationRange(self, v):
+        _check(self.lib.sf_bf_set_rotation_range(self.h, C.c_float(v)))
+
+    def setMeanErrorThreshold(self, v):
+        _check(self.lib.sf_bf_set_mean_error_threshold(self.h, C.c_float(v)))
+
+    def setInitialGuess(self, T):
+        T = _f32(T).reshape(16)
+        _check(self.lib.sf_bf_set_initial_guess(self.h, _p(T)))
+
+    def setSourceCloud(self, cloud):
+        if isinstance(cloud, Cloud):
+            _check(self.lib.sf_bf_set_source_cloud(self.h, cloud.h))
+        else:
+            xyz = _f32(cloud).reshape(-1, 3)
+            _check(self.lib.sf_bf_set_source(self.h, _p(xyz), C.c_int64(len(xyz))))
+
+    def setTargetCloud(self, target):
+        if isinstance(target, Map):
+            self._map = target
+            _check(self.lib.sf_bf_set_target_map(self.h, target.h))
+        else:
+            xyz = _f32(target).reshape(-1, 3)
+            _check(self.lib.sf_bf_set_target(self.h, _p(xyz), C.c_int64(len(xyz))))
+
+    def resetFirstAlignment(self, value):
+        _check(self.lib.sf_bf_reset_first_alignment(self.h, C.c_int(int(value))))
+
+    def alignClouds(self):
+        found = C.c_int()
+        _check(self.lib.sf_bf_align_clouds(self.h, C.byref(found)))
+        return bool(found.value)
+
+    def firstAlignmentCompleted(self):
+        return bool(self.lib.sf_bf_first_alignment_completed(self.h))
+
+    def getBestTransformation(self):
+        T = np.empty(16, np.float32)
+        _check(self.lib.sf_bf_get_best_transformation(self.h, _p(T)))
+        return T.reshape(4, 4)
+
+    def last_result(self):
+        idx, score, ncand = C.c_int32(), C.c_float(), C.c_int32()
+        _check(self.lib.sf_bf_last_result(self.h, C.byref(idx), C.byref(score), C.byref(ncand), None, C.c_int64(0)))
+        scores = np.empty(max(ncand.value, 1), np.float32)
+        _check(self.lib.sf_bf_last_result(self.h, None, None, None, _p(scores), C.c_int64(len(scores))))
+        return dict(index=idx.value, score=score.value, n_candidates=ncand.value, scores=scores[:ncand.value])
+
+    def close(self):
+        if self.h:
+            self.lib.sf_bf_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):
