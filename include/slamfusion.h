@@ -88,6 +88,18 @@ int sf_cloud_transform(sf_cloud *c, const float T[16]);
 /* indices (into the cloud before the call) kept by the LAST crop/subsample on this cloud */
 int sf_cloud_last_indices(sf_cloud *c, int32_t *idx, int64_t cap, int64_t *n);
 
+/* f-2: PointCloud2 -> xyz on the device (pcl::fromROSMsg, localization_node.cpp:290-291;
+ * pc2.read_points, localization_node.py:106-111): raw little-endian message buffer,
+ * n_points = width*height, float32 fields at byte offsets off_x/y/z inside point_step */
+int sf_cloud_from_pointcloud2(sf_cloud *c, const void *data, int64_t n_points, int point_step, int off_x, int off_y, int off_z);
+/* f-3: PCD v0.7 files (ascii / binary / binary_compressed read; "DATA binary" write exactly
+ * as pcl::io::savePCDFileBinary does for PointXYZ — mapping/src/map_data_save_node.cpp:74) */
+int sf_cloud_load_pcd(sf_cloud *c, const char *path);
+int sf_cloud_save_pcd(sf_cloud *c, const char *path);
+int sf_pcd_read(const char *path, float **xyz, int64_t *n); /* caller frees with sf_free */
+int sf_pcd_write_binary(const char *path, const float *xyz, int64_t n);
+void sf_free(void *p);
+
 /* a4 / a5: voxel grids.  flavour SF_VOXEL_PCL = pcl::VoxelGrid float32
  * (global_map_frames_manager.cpp:142-146): int32 linear index, ascending-index output,
  * on int32 overflow the cloud is left unchanged and *status_flags gets
@@ -234,6 +246,19 @@ int sf_bf_get_best_transformation(sf_bf *bf, float T[16]);
 /* diagnostics of the last alignClouds: chosen candidate (nesting-order index), its score,
  * and the float32 score of every candidate evaluated before the early exit (NaN after it) */
 int sf_bf_last_result(sf_bf *bf, int32_t *index, float *score, int32_t *n_candidates, float *scores, int64_t cap);
+
+/* ------------------------------------------------------------------ GlobalMapFramesManager (start-up I/O) */
+/* localization/src/global_map_frames_manager.cpp: map.pcd cache or merge of the recorded
+ * cloud_<n>.pcd tiles + PCL voxel grid (on the device) + save (:93-151); map_T_global from
+ * odometry_positions.txt / gps_imu_poses.txt with the bad-reading filter (:153-248);
+ * altitude look-up table (:60-63, :69-91). */
+typedef struct sf_frames sf_frames;
+sf_frames *sf_frames_create(const char *data_folder, const char *map_name, int64_t num_poses_max);
+void sf_frames_destroy(sf_frames *fr);
+int sf_frames_get_map_cloud(sf_frames *fr, sf_cloud *out, float voxel_size, int *loaded_cached);
+int sf_frames_get_map_T_global(sf_frames *fr, double T[16]);
+float sf_frames_get_closest_altitude(sf_frames *fr, double lat, double lon);
+int sf_frames_altitude_table(sf_frames *fr, double *table_lat_lon_alt, int64_t cap_rows, int64_t *rows);
 
 /* ------------------------------------------------------------------ pose fusion (host, float32 like the reference) */
 /* a14: computePosePredictionFromOdometry — localization_node.cpp:89-110 */

@@ -153,6 +153,25 @@ class Cloud:
         _check(self.lib.sf_cloud_upload(self.h, _p(xyz), C.c_int64(len(xyz))))
         return self
 
+    def from_pointcloud2(self, msg):
+        """PointCloud2-like message (width, height, point_step, fields or x/y/z at 0/4/8, data)."""
+        n = int(msg.width) * int(msg.height)
+        offs = {"x": 0, "y": 4, "z": 8}
+        for f in getattr(msg, "fields", []) or []:
+            if f.name in offs:
+                offs[f.name] = int(f.offset)
+        buf = np.frombuffer(msg.data, dtype=np.uint8)
+        _check(self.lib.sf_cloud_from_pointcloud2(self.h, _p(buf), C.c_int64(n), C.c_int(int(msg.point_step)),
+                                                  C.c_int(offs["x"]), C.c_int(offs["y"]), C.c_int(offs["z"])))
+        return self
+
+    def load_pcd(self, path):
+        _check(self.lib.sf_cloud_load_pcd(self.h, str(path).encode()))
+        return self
+
+    def save_pcd(self, path):
+        _check(self.lib.sf_cloud_save_pcd(self.h, str(path).encode()))
+
     def from_device(self, ptr, n):
         _check(self.lib.sf_cloud_from_device(self.h, C.c_void_p(ptr), C.c_int64(n)))
         return self
@@ -534,6 +553,60 @@ class BruteForceAlignment:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+def pcd_read(path):
+    lib = load_library()
+    ptr, n = C.POINTER(C.c_float)(), C.c_int64()
+    _check(lib.sf_pcd_read(str(path).encode(), C.byref(ptr), C.byref(n)))
+    out = np.ctypeslib.as_array(ptr, shape=(max(n.value, 1) * 3,))[:n.value * 3].reshape(-1, 3).copy()
+    lib.sf_free(ptr)
+    return out
+
+
+def pcd_write_binary(path, xyz):
+    xyz = _f32(xyz).reshape(-1, 3)
+    _check(load_library().sf_pcd_write_binary(str(path).encode(), _p(xyz), C.c_int64(len(xyz))))
+
+
+class GlobalMapFramesManager:
+    """sf_frames: GlobalMapFramesManager of localization/src/global_map_frames_manager.cpp."""
+
+    def __init__(self, data_folder, map_name="map", num_poses_max=50):
+        self.lib = load_library()
+        self.lib.sf_frames_create.restype = C.c_void_p
+        self.lib.sf_frames_get_closest_altitude.restype = C.c_float
+        self.h = C.c_void_p(self.lib.sf_frames_create(str(data_folder).encode(), str(map_name).encode(), C.c_int64(num_poses_max)))
+
+    def getMapCloud(self, ctx, voxel_size=0.1):
+        cloud = Cloud(ctx)
+        cached = C.c_int()
+        _check(self.lib.sf_frames_get_map_cloud(self.h, cloud.h, C.c_float(voxel_size), C.byref(cached)))
+        self.loaded_cached = bool(cached.value)
+        return cloud
+
+    def getMapTGlobal(self):
+        T = np.empty(16, np.float64)
+        _check(self.lib.sf_frames_get_map_T_global(self.h, _p(T)))
+        return T.reshape(4, 4)
+
+    def getClosestAltitude(self, lat, lon):
+        return float(self.lib.sf_frames_get_closest_altitude(self.h, C.c_double(lat), C.c_double(lon)))
+
+    def altitude_table(self):
+        rows = C.c_int64()
+        _check(self.lib.sf_frames_altitude_table(self.h, None, C.c_int64(0), C.byref(rows)))
+        tab = np.empty((max(rows.value, 1), 3), np.float64)
+        _check(self.lib.sf_frames_altitude_table(self.h, _p(tab), C.c_int64(len(tab)), C.byref(rows)))
+        return tab[:rows.value]
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.sf_frames_destroy(self.h)
+                self.h = None
         except Exception:
             pass
 

@@ -602,3 +602,41 @@ int cloud_minmax(sf_ctx *ctx, const float *d_xyz, int64_t n, MinMaxHost *out)
     return SF_OK;
 }
 } // namespace sf
+
+// ------------------------------------------------------------------ PointCloud2 unpack
+// pcl::fromROSMsg (localization/src/localization_node.cpp:290-291) / pc2.read_points
+// (localization_python/.../localization_node.py:106-111) on the device: the raw message buffer
+// is uploaded once and the x, y, z float32 fields are gathered from their byte offsets.
+namespace {
+__global__ void k_unpack_pc2(const uint8_t *__restrict__ raw, int64_t n, int point_step, int ox, int oy, int oz, float *__restrict__ xyz)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = raw + (size_t)i * point_step;
+    auto rd = [&](int off) -> float { // byte-wise: fields need not be 4-byte aligned in the message
+        uint32_t v = (uint32_t)p[off] | ((uint32_t)p[off + 1] << 8) | ((uint32_t)p[off + 2] << 16) | ((uint32_t)p[off + 3] << 24);
+        return __uint_as_float(v);
+    };
+    xyz[3 * i] = rd(ox); xyz[3 * i + 1] = rd(oy); xyz[3 * i + 2] = rd(oz);
+}
+} // namespace
+
+extern "C" int sf_cloud_from_pointcloud2(sf_cloud *c, const void *data, int64_t n_points, int point_step, int off_x, int off_y, int off_z)
+{
+    SF_CHECK(c && n_points >= 0 && (data || n_points == 0), SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(point_step >= 12 && off_x >= 0 && off_y >= 0 && off_z >= 0 && off_x + 4 <= point_step && off_y + 4 <= point_step && off_z + 4 <= point_step,
+             SF_ERR_INVALID, "field offsets do not fit point_step %d", point_step);
+    SF_HIP(hipSetDevice(c->ctx->device));
+    SF_TRY(c->xyz.reserve(sizeof(float) * 3 * (size_t)(n_points > 0 ? n_points : 1)));
+    if (n_points > 0) {
+        sf::DevBuf raw;
+        SF_TRY(raw.reserve((size_t)n_points * (size_t)point_step));
+        SF_HIP(hipMemcpyAsync(raw.p, data, (size_t)n_points * (size_t)point_step, hipMemcpyHostToDevice, c->ctx->stream));
+        hipLaunchKernelGGL(k_unpack_pc2, dim3(nblk(n_points)), dim3(256), 0, c->ctx->stream, raw.as<uint8_t>(), n_points, point_step, off_x, off_y, off_z, c->xyz.as<float>());
+        SF_HIP(hipStreamSynchronize(c->ctx->stream));
+        raw.release();
+    }
+    c->n = n_points;
+    cloud_reset_meta(c);
+    return SF_OK;
+}

@@ -1,7 +1,8 @@
 """The C++ node's per-scan orchestration (localization/src/localization_node.cpp:263-344)
 over the C ABI: same order, same constants, same state variables — minus the ROS 2 shell
-(rclcpp, message_filters, publishers: out of scope) and minus the
-start-up BruteForceAlignment (a §8(f-1) "next" row; callers pass the initial lock).
+(rclcpp, message_filters, publishers: out of scope).  The start-up lock
+(performCoarseAlignment: BruteForceAlignment, then the "strong" ICP) is included; callers that
+already hold a lock set `coarse_alignment_complete_ = True`.
 
 Host work (a14-a18, microseconds) runs in libslamfusion's C++ fusion functions; device
 work is subsample -> radius crop -> (window change) -> ICP.  The reference re-crops the map and
@@ -31,6 +32,14 @@ class LocalizationFlow:
         self.icp_ = api.Icp(ctx, 0.5, 10, 0.05, 1e-5)        # :24-28
         self.icp_.set_target(self.map_index_)
         self.coarse_pose_filter_ = api.StochasticFilter(4, 3.0)   # :32-34
+        self.brute_force_alignment_ = api.BruteForceAlignment(ctx)   # :38-43
+        self.brute_force_alignment_.setMeanErrorThreshold(0.1)
+        self.brute_force_alignment_.setXYZStep(0.1, 0.1, 0.05)
+        self.brute_force_alignment_.setXYZRange(1.5, 1.5, 0.1)
+        self.brute_force_alignment_.setRotationStep(np.pi / 18.0)
+        self.brute_force_alignment_.setRotationRange(np.pi / 6.0)
+        self.coarse_alignment_complete_ = False
+        self.ref_cropped_map_cloud_ = None
         self.map_T_sensor_ = np.eye(4, dtype=np.float32)
         self.odom_T_sensor_previous_ = np.eye(4, dtype=np.float32)
         self.map_T_ref_ = np.eye(4, dtype=np.float32)
@@ -45,6 +54,49 @@ class LocalizationFlow:
     def computeGpsCoarsePoseInMapFrame(self, lat, lon):      # :112-128
         alt = api.closest_altitude(self.altitude_table_, lat, lon)
         return api.gps_pose(self.map_T_global_, self.current_compass_yaw_, lat, lon, alt)
+
+    def performCoarseAlignment(self, scan_cloud):
+        """localization_node.cpp:200-261: brute force over the pose grid, else the "strong" ICP."""
+        bf = self.brute_force_alignment_
+        if bf.firstAlignmentCompleted():
+            return True
+        if self.ref_cropped_map_cloud_ is None:              # cropPointCloudThroughRadius output, PCL order (:302)
+            self.ref_cropped_map_cloud_ = self.map_cloud_.copy().crop_radius(self.map_T_ref_[:3, 3], self.cloud_crop_radius_, sorted=True)
+        map_cloud_temp = self.ref_cropped_map_cloud_.copy()
+        scan_cloud_temp = scan_cloud.copy()
+        map_cloud_temp.subsample(15)                          # :211
+        map_cloud_temp.remove_floor()                         # :212
+        scan_cloud_temp.remove_floor()                        # :213
+        bf.setInitialGuess(self.map_T_sensor_)
+        bf.setSourceCloud(scan_cloud_temp)
+        self._coarse_map_ = api.Map(self.ctx, map_cloud_temp, 0.0)
+        bf.setTargetCloud(self._coarse_map_)
+        self.last_coarse = dict(n_map=len(map_cloud_temp), n_scan=len(scan_cloud_temp))
+        if not bf.alignClouds():
+            # :221-247 — the ICP keeps this sparse target until the next re-crop, like the reference
+            self.icp_.set_target(self._coarse_map_)
+            self.icp_.set_source(scan_cloud_temp)
+            self.icp_.set_initial_transformation(bf.getBestTransformation())
+            self.icp_.set_max_correspondence_dist(5.0)
+            self.icp_.set_transformation_epsilon(1e-2)
+            self.icp_.set_acceptable_mean_error(0.4)
+            self.icp_.set_num_iterations(80)
+            icp_result = self.icp_.align("ref_cpp")
+            self.last_coarse["icp"] = icp_result
+            if icp_result["converged"]:
+                self.icp_.set_max_correspondence_dist(0.5)
+                self.icp_.set_transformation_epsilon(1e-5)
+                self.icp_.set_acceptable_mean_error(0.05)
+                self.icp_.set_num_iterations(10)
+                bf.resetFirstAlignment(True)
+                self.coarse_alignment_complete_ = True
+                self.map_T_sensor_ = icp_result["T"]
+                return True
+            bf.resetFirstAlignment(False)
+            return False
+        self.coarse_alignment_complete_ = True
+        self.map_T_sensor_ = bf.getBestTransformation()
+        return True
 
     def localizationCallback(self, scan_xyz, gps, odom):
         """gps = dict(latitude, longitude, altitude, position_covariance[9]);
@@ -66,8 +118,15 @@ class LocalizationFlow:
         sensor_T_ref = api.mat4f_mul(api.mat4f_inverse(self.map_T_sensor_), self.map_T_ref_)
         if np.linalg.norm(sensor_T_ref[:3, 3].astype(np.float32)) > self.ref_frame_distance_ or not self.have_window_:
             self.map_index_.window_sphere(self.map_T_sensor_[:3, 3], self.cloud_crop_radius_)
+            self.icp_.set_target(self.map_index_)             # icp_->setTargetPointCloud(ref_cropped_map_cloud_), :303
+            self.ref_cropped_map_cloud_ = None               # materialised only if the coarse phase needs it
             self.map_T_ref_ = self.map_T_sensor_.copy()
             self.have_window_ = True
+
+        # COARSE ALIGNMENT :307-315
+        if not self.coarse_alignment_complete_:
+            if not self.performCoarseAlignment(scan):
+                return None
 
         # FINE ALIGNMENT :318-338
         map_T_sensor_odom = api.odom_prediction(self.map_T_sensor_, self.odom_T_sensor_previous_, odom_T_sensor_current)
