@@ -120,21 +120,12 @@ struct SfGrid {
     const uint32_t *cell_start; // [ncell + 1]
     const float4 *pts;          // sorted by cell: x, y, z, bitcast(original index)
     const float4 *nrm;          // sorted normals (w = neighbour count) or nullptr
-    const float4 *bkt;          // optional cell buckets, 8 x float4 = 128 B per cell (sf_map.hip), or nullptr
     int64_t n;
 };
 
-// One 128-byte bucket per grid cell (one cache line = one memory request per visited cell,
-// no cell_start indirection): up to 4 points, structure-of-arrays inside the line:
-//   [0] x0..x3  [1] y0..y3  [2] z0..z3  [3] j0..j3 (sorted position; -1 empty; j3 == -2: cell
-//   holds more than 4 points -> use the CSR range)   [4] nx0..3  [5] ny0..3  [6] nz0..3  [7] unused
-// Empty slots carry x = +inf so their distance never wins.
-constexpr int SF_BKT_SLOTS = 4;
-constexpr int SF_BKT_F4 = 8;
-
 struct sf_map {
     sf_ctx *ctx = nullptr;
-    sf::DevBuf pts4, nrm4, cell_start, keys, vals, keys2, vals2, inv_perm, buckets;
+    sf::DevBuf pts4, nrm4, cell_start, keys, vals, keys2, vals2, inv_perm;
     int64_t n = 0;
     bool built = false, has_normals = false;
     SfGrid grid{};

@@ -440,41 +440,35 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
     __shared__ double stage[BLK / 64][32];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool ok = hit.j >= 0;
-    const double tx = hit.px, ty = hit.py, tz = hit.pz;
-    const double ex = sx - tx, ey = sy - ty, ez = sz - tz;
+    // only the winner's normal is fetched after the search; its coordinates come in registers
+    float4 tn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok && MODE == 2) tn = g.nrm[hit.j];
+    // lanes without a correspondence contribute exact zeros: e = 0 and n = 0 zero every product
+    const double wgt = ok ? 1.0 : 0.0;
+    const double tx = ok ? (double)hit.px : 0.0, ty = ok ? (double)hit.py : 0.0, tz = ok ? (double)hit.pz : 0.0;
+    const double ex = ok ? sx - tx : 0.0, ey = ok ? sy - ty : 0.0, ez = ok ? sz - tz : 0.0;
     const double d2 = ex * ex + ey * ey + ez * ez;
     if (MODE == 1) {
+        const double ux = ok ? sx : 0.0, uy = ok ? sy : 0.0, uz = ok ? sz : 0.0; // s, zeroed for dead lanes
         double v[16];
-        v[0] = 1.0;
-        v[1] = sx; v[2] = sy; v[3] = sz;
+        v[0] = wgt;
+        v[1] = ux; v[2] = uy; v[3] = uz;
         v[4] = tx; v[5] = ty; v[6] = tz;
-        v[7] = sx * tx; v[8] = sx * ty; v[9] = sx * tz;
-        v[10] = sy * tx; v[11] = sy * ty; v[12] = sy * tz;
-        v[13] = sz * tx; v[14] = sz * ty; v[15] = sz * tz;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = ok ? v[c] : 0.0;
+        v[7] = ux * tx; v[8] = ux * ty; v[9] = ux * tz;
+        v[10] = uy * tx; v[11] = uy * ty; v[12] = uy * tz;
+        v[13] = uz * tx; v[14] = uz * ty; v[15] = uz * tz;
         const double t0 = wave_reduce_16(v);
-        const double t1 = wave_reduce_1(ok ? d2 : 0.0);
+        const double t1 = wave_reduce_1(d2);
         if ((lane & 3) == 0) stage[wv][lane >> 2] = t0;
         if (lane == 0) stage[wv][16] = t1;
     } else {
-        float nfx = 0.0f, nfy = 0.0f, nfz = 1.0f;
-        if (ok) {
-            // the winner's normal: from the bucket line it was found in, or the sorted normal array
-            if (hit.bcell >= 0) {
-                const float *bf = reinterpret_cast<const float *>(g.bkt + (size_t)hit.bcell * SF_BKT_F4);
-                nfx = bf[16 + hit.bslot]; nfy = bf[20 + hit.bslot]; nfz = bf[24 + hit.bslot];
-            } else {
-                const float4 nf = g.nrm[hit.j];
-                nfx = nf.x; nfy = nf.y; nfz = nf.z;
-            }
-        }
-        const double nx = nfx, ny = nfy, nz = nfz;
+        const double nx = tn.x, ny = tn.y, nz = tn.z;  // zero for dead lanes -> J = 0, r = 0
         const double r = ex * nx + ey * ny + ez * nz;
-        const double J[6] = {sy * nz - sz * ny, sz * nx - sx * nz, sx * ny - sy * nx, nx, ny, nz};
+        const double ux = ok ? sx : 0.0, uy = ok ? sy : 0.0, uz = ok ? sz : 0.0; // a non-finite dead query must not turn 0 * s into NaN
+        const double J[6] = {uy * nz - uz * ny, uz * nx - ux * nz, ux * ny - uy * nx, nx, ny, nz};
         {   // record[0..15] = n, sum r^2, JtJ (0,0) (0,1) .. (0,5) (1,1) .. (1,5) (2,2) (2,3) (2,4)
             double v[16];
-            v[0] = 1.0;
+            v[0] = wgt;
             v[1] = r * r;
             int k = 2;
 #pragma unroll
@@ -485,8 +479,6 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
                     ++k;
                 }
             }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] = ok ? v[c] : 0.0;
             const double t0 = wave_reduce_16(v);
             if ((lane & 3) == 0) stage[wv][lane >> 2] = t0;
         }
@@ -506,8 +498,6 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
             v[13] = d2;
             v[14] = 0.0;
             v[15] = 0.0;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] = ok ? v[c] : 0.0;
             const double t1 = wave_reduce_16(v);
             if ((lane & 3) == 0) stage[wv][16 + (lane >> 2)] = t1;
         }

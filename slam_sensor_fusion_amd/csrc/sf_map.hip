@@ -12,7 +12,6 @@
 
 #include <rocprim/rocprim.hpp>
 #include <cmath>
-#include <cstdlib>
 
 namespace {
 
@@ -57,55 +56,6 @@ __global__ void k_cell_bounds(const uint32_t *__restrict__ keys, int64_t n_valid
         for (uint32_t c = k + 1; c <= ncell; ++c) cell_start[c] = (uint32_t)n_valid;
 }
 
-// one thread per cell: copy its (<= 4) points into the cell's 128-byte bucket
-__global__ void k_fill_buckets(const uint32_t *__restrict__ cell_start, const float4 *__restrict__ pts4, uint32_t ncell, float4 *__restrict__ bkt)
-{
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncell) return;
-    const uint32_t a = cell_start[c], b = cell_start[c + 1];
-    const uint32_t cnt = b - a;
-    float x[4], y[4], z[4];
-    int j[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { x[s] = INFINITY; y[s] = 0.0f; z[s] = 0.0f; j[s] = -1; }
-    if (cnt <= 4) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            if ((uint32_t)s < cnt) {
-                const float4 p = pts4[a + s];
-                x[s] = p.x; y[s] = p.y; z[s] = p.z; j[s] = (int)(a + s);
-            }
-    } else {
-        j[3] = -2; // overflow: searched through the CSR range instead
-    }
-    float4 *o = bkt + (size_t)c * SF_BKT_F4;
-    o[0] = make_float4(x[0], x[1], x[2], x[3]);
-    o[1] = make_float4(y[0], y[1], y[2], y[3]);
-    o[2] = make_float4(z[0], z[1], z[2], z[3]);
-    o[3] = make_float4(__int_as_float(j[0]), __int_as_float(j[1]), __int_as_float(j[2]), __int_as_float(j[3]));
-    o[4] = o[5] = o[6] = o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-__global__ void k_fill_bucket_normals(const uint32_t *__restrict__ cell_start, const float4 *__restrict__ nrm4, uint32_t ncell, float4 *__restrict__ bkt)
-{
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncell) return;
-    const uint32_t a = cell_start[c], b = cell_start[c + 1];
-    const uint32_t cnt = b - a;
-    if (cnt == 0 || cnt > 4) return;
-    float nx[4] = {0, 0, 0, 0}, ny[4] = {0, 0, 0, 0}, nz[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if ((uint32_t)s < cnt) {
-            const float4 v = nrm4[a + s];
-            nx[s] = v.x; ny[s] = v.y; nz[s] = v.z;
-        }
-    float4 *o = bkt + (size_t)c * SF_BKT_F4;
-    o[4] = make_float4(nx[0], nx[1], nx[2], nx[3]);
-    o[5] = make_float4(ny[0], ny[1], ny[2], ny[3]);
-    o[6] = make_float4(nz[0], nz[1], nz[2], nz[3]);
-}
-
 __global__ void k_fill_u32(uint32_t *p, int64_t n, uint32_t v)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -145,7 +95,7 @@ extern "C" void sf_map_destroy(sf_map *m)
     hipError_t e = hipStreamSynchronize(m->ctx->stream);
     (void)e;
     m->pts4.release(); m->nrm4.release(); m->cell_start.release(); m->keys.release(); m->vals.release();
-    m->keys2.release(); m->vals2.release(); m->inv_perm.release(); m->buckets.release();
+    m->keys2.release(); m->vals2.release(); m->inv_perm.release();
     sf_ctx *ctx = m->ctx;
     delete m;
     sf::ctx_release(ctx);
@@ -227,23 +177,11 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
         hipLaunchKernelGGL(k_cell_bounds, dim3(nblk(n_valid)), dim3(256), 0, st, m->keys2.as<uint32_t>(), n_valid, g.ncell, cs);
     else
         hipLaunchKernelGGL(k_fill_u32, dim3(nblk((int64_t)g.ncell + 2)), dim3(256), 0, st, cs, (int64_t)g.ncell + 2, 0u);
-    // optional bucket image of the grid (one 128-B line per cell).  Skipped when it would be
-    // large compared with the map (sparse maps) or when SF_MAP_BUCKETS=0.
-    const char *env = getenv("SF_MAP_BUCKETS");
-    const bool want_bkt = env && env[0] == '1'; // opt-in: measured slower than the CSR rows on MI355X
-    const size_t bkt_bytes = (size_t)g.ncell * SF_BKT_F4 * sizeof(float4);
-    bool have_bkt = false;
-    if (want_bkt && n_valid > 0 && bkt_bytes <= ((size_t)16 << 30) && (double)g.ncell <= 8.0 * (double)n_valid) {
-        SF_TRY(m->buckets.reserve(bkt_bytes));
-        hipLaunchKernelGGL(k_fill_buckets, dim3(nblk((int64_t)g.ncell)), dim3(256), 0, st, cs, m->pts4.as<float4>(), g.ncell, m->buckets.as<float4>());
-        have_bkt = true;
-    }
     SF_HIP(hipGetLastError());
     SF_HIP(hipStreamSynchronize(st));
 
     m->n = n;
     SfGrid &G = m->grid;
-    G.bkt = have_bkt ? m->buckets.as<float4>() : nullptr;
     for (int d = 0; d < 3; ++d) { G.org[d] = g.org[d]; G.dim[d] = dim[d]; }
     G.inv_h = g.inv_h;
     G.h = (float)h;
@@ -472,10 +410,6 @@ extern "C" int sf_map_estimate_normals(sf_map *m, float radius)
     const int R = std::max(1, (int)std::ceil((double)radius / (double)m->grid.h - 1e-9));
     if (m->grid.n > 0)
         hipLaunchKernelGGL(k_normals, dim3(nblk(m->grid.n)), dim3(256), 0, ctx->stream, m->grid, (double)radius * (double)radius, R, m->nrm4.as<float4>());
-    if (m->grid.bkt) {
-        const uint32_t ncell = (uint32_t)((uint64_t)m->grid.dim[0] * m->grid.dim[1] * m->grid.dim[2]);
-        hipLaunchKernelGGL(k_fill_bucket_normals, dim3(nblk((int64_t)ncell)), dim3(256), 0, ctx->stream, m->grid.cell_start, m->nrm4.as<float4>(), ncell, m->buckets.as<float4>());
-    }
     SF_HIP(hipGetLastError());
     SF_HIP(hipStreamSynchronize(ctx->stream));
     m->grid.nrm = m->nrm4.as<float4>();
@@ -495,10 +429,6 @@ extern "C" int sf_map_set_normals(sf_map *m, const float *normals, int64_t n)
     SF_HIP(hipMemcpyAsync(tmp.p, normals, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     if (m->grid.n > 0)
         hipLaunchKernelGGL(k_normals_from_host_order, dim3(nblk(m->grid.n)), dim3(256), 0, ctx->stream, m->grid, tmp.as<float>(), m->nrm4.as<float4>());
-    if (m->grid.bkt) {
-        const uint32_t ncell = (uint32_t)((uint64_t)m->grid.dim[0] * m->grid.dim[1] * m->grid.dim[2]);
-        hipLaunchKernelGGL(k_fill_bucket_normals, dim3(nblk((int64_t)ncell)), dim3(256), 0, ctx->stream, m->grid.cell_start, m->nrm4.as<float4>(), ncell, m->buckets.as<float4>());
-    }
     SF_HIP(hipStreamSynchronize(ctx->stream));
     tmp.release();
     m->grid.nrm = m->nrm4.as<float4>();

@@ -5,20 +5,18 @@
 // Open3D hybrid search behind localization_python/.../localization_node.py:233-237.
 // One lane per query.
 //
-// Measured on MI355X (profiles/): this path is bound by the RATE OF MEMORY REQUESTS that
-// leave the CU (random gathers over a working set far larger than the 4 MiB per-XCD L2:
-// L2 hit rate 16 %, ~56 G requests/s chip-wide at saturation), not by HBM bandwidth and not
-// by instruction issue.  So the layout is chosen to minimise cache lines per query:
-//
-//   ring 1, bucket path (SfGrid.bkt): every grid cell owns one 128-byte line holding up to
-//     4 points (SoA inside the line) + their normals: visiting a cell is ONE request with no
-//     cell_start indirection.  The query's own cell first, then only those of the 26
-//     neighbours whose gap to the query is smaller than the best distance so far — the
-//     neighbour list is per-LANE data (a bit mask walked with ffs), and the next cell's line
-//     is requested before the current one is evaluated.
-//   CSR path (cells with > 4 points, rings >= 2, maps without buckets): the map is sorted by
-//     cell (x fastest), so the 2R+1 cells of one (y,z) row are one contiguous candidate
-//     range [cell_start[row+x0], cell_start[row+x1+1]); candidates fetched four at a time.
+// Measured on MI355X (profiles/): the kernel is bound by vector-instruction issue
+// under heavy lane divergence (every lane walks its own short candidate lists) with dependent
+// gather round trips behind it, not by HBM bandwidth.  Hence: the map is sorted by cell
+// (x fastest) so a row of cells is one contiguous candidate range; ONE 16-byte look-up returns
+// the bounds of the three cells of a row; the query's own cell is scanned first and the x
+// neighbours / the 8 neighbouring rows only while their gap to the query is smaller than the
+// best distance so far; the rows a query still needs are per-LANE data (a bit mask walked with
+// ffs) and the next row's bounds are requested before the current row is scanned; candidates are
+// fetched four at a time with unconditional (clamped) loads so they are in flight together;
+// the winner's coordinates stay in registers (re-reading them after the search costs a round trip).
+// A per-cell 128-byte bucket layout (one line per visited cell, no bounds look-up) was built
+// and measured: fewer memory requests, but more instructions — slower.
 //
 // Exactness: after scanning the block of radius R around the query's cell, every
 // unscanned point is at least m = distance(query, block boundary) away; the search stops
@@ -31,11 +29,9 @@
 namespace sf {
 
 struct NNHit {
-    float d2;      // squared distance of the best candidate (== threshold if none)
-    int j;         // sorted position of the best candidate, -1 if none
-    float px, py, pz; // its coordinates
-    int bcell;     // bucket (cell id) the winner was read from, -1 if it came through the CSR path
-    int bslot;     // slot inside that bucket
+    float d2;         // squared distance of the best candidate (== threshold if none)
+    int j;            // sorted position of the best candidate, -1 if none
+    float px, py, pz; // its coordinates (kept in registers: re-reading the winner costs a round trip)
 };
 
 __device__ __forceinline__ float l2_simple(float qx, float qy, float qz, float px, float py, float pz)
@@ -64,8 +60,7 @@ __device__ __forceinline__ bool window_accepts(const SfWindow &w, float px, floa
 }
 
 template <bool WINDOW>
-__device__ __forceinline__ void consider(const SfWindow &w, float px, float py, float pz, int j, int bcell, int bslot, bool valid, float qx, float qy, float qz,
-                                         NNHit &hit)
+__device__ __forceinline__ void consider(const SfWindow &w, float px, float py, float pz, int j, bool valid, float qx, float qy, float qz, NNHit &hit)
 {
     const float d2 = l2_simple(qx, qy, qz, px, py, pz);
     if (valid && d2 < hit.d2) {
@@ -73,8 +68,6 @@ __device__ __forceinline__ void consider(const SfWindow &w, float px, float py, 
             hit.d2 = d2;
             hit.j = j;
             hit.px = px; hit.py = py; hit.pz = pz;
-            hit.bcell = bcell;
-            hit.bslot = bslot;
         }
     }
 }
@@ -89,10 +82,10 @@ __device__ __forceinline__ void scan_range(const SfGrid &g, const SfWindow &w, u
         const uint32_t last = b - 1;
         const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
         const float4 p0 = g.pts[j], p1 = g.pts[j1], p2 = g.pts[j2], p3 = g.pts[j3];
-        consider<WINDOW>(w, p0.x, p0.y, p0.z, (int)j, -1, 0, true, qx, qy, qz, hit);
-        consider<WINDOW>(w, p1.x, p1.y, p1.z, (int)j1, -1, 0, j + 1 < b, qx, qy, qz, hit);
-        consider<WINDOW>(w, p2.x, p2.y, p2.z, (int)j2, -1, 0, j + 2 < b, qx, qy, qz, hit);
-        consider<WINDOW>(w, p3.x, p3.y, p3.z, (int)j3, -1, 0, j + 3 < b, qx, qy, qz, hit);
+        consider<WINDOW>(w, p0.x, p0.y, p0.z, (int)j, true, qx, qy, qz, hit);
+        consider<WINDOW>(w, p1.x, p1.y, p1.z, (int)j1, j + 1 < b, qx, qy, qz, hit);
+        consider<WINDOW>(w, p2.x, p2.y, p2.z, (int)j2, j + 2 < b, qx, qy, qz, hit);
+        consider<WINDOW>(w, p3.x, p3.y, p3.z, (int)j3, j + 3 < b, qx, qy, qz, hit);
     }
 }
 
@@ -115,30 +108,6 @@ __device__ __forceinline__ void scan_row(const SfGrid &g, const SfWindow &w, con
     if (xp && (gap2yz + gxp2) * 0.998f < hit.d2) scan_range<WINDOW>(g, w, rb.s2, rb.s3, qx, qy, qz, hit);
 }
 
-struct Bucket { float4 x, y, z, j; };
-
-__device__ __forceinline__ Bucket load_bucket(const SfGrid &g, int cell)
-{
-    const float4 *b = g.bkt + (size_t)cell * SF_BKT_F4;
-    Bucket r;
-    r.x = b[0]; r.y = b[1]; r.z = b[2]; r.j = b[3];
-    return r;
-}
-
-template <bool WINDOW>
-__device__ __forceinline__ void scan_bucket(const SfGrid &g, const SfWindow &w, int cell, const Bucket &b, float qx, float qy, float qz, NNHit &hit)
-{
-    const int j0 = __float_as_int(b.j.x), j1 = __float_as_int(b.j.y), j2 = __float_as_int(b.j.z), j3 = __float_as_int(b.j.w);
-    if (j3 == -2) { // more than 4 points in this cell: CSR range of the single cell
-        scan_range<WINDOW>(g, w, g.cell_start[cell], g.cell_start[cell + 1], qx, qy, qz, hit);
-        return;
-    }
-    consider<WINDOW>(w, b.x.x, b.y.x, b.z.x, j0, cell, 0, j0 >= 0, qx, qy, qz, hit);
-    consider<WINDOW>(w, b.x.y, b.y.y, b.z.y, j1, cell, 1, j1 >= 0, qx, qy, qz, hit);
-    consider<WINDOW>(w, b.x.z, b.y.z, b.z.z, j2, cell, 2, j2 >= 0, qx, qy, qz, hit);
-    consider<WINDOW>(w, b.x.w, b.y.w, b.z.w, j3, cell, 3, j3 >= 0, qx, qy, qz, hit);
-}
-
 // distance (in cells, >= 0) from grid coordinate gc to the cell interval [c, c+1]
 __device__ __forceinline__ float cell_gap(float gc, int c, int cq)
 {
@@ -146,13 +115,6 @@ __device__ __forceinline__ float cell_gap(float gc, int c, int cq)
     float d = c < cq ? gc - (float)(c + 1) : (float)c - gc;
     return d > 0.0f ? d : 0.0f;
 }
-
-// the 26 neighbours of a cell: 6 faces, 12 edges, 8 corners; per-axis (offset + 1) packed
-// in 2-bit fields of one 64-bit constant each (no table in memory)
-constexpr unsigned long long NB_OXP = 0x8888558888558ull;
-constexpr unsigned long long NB_OYP = 0xa0a08855a0585ull;
-constexpr unsigned long long NB_OZP = 0xaa00a0a055855ull;
-__device__ __forceinline__ int nb_off(unsigned long long packed, int k) { return (int)((packed >> (2 * k)) & 3ull) - 1; }
 
 // thr: candidates are accepted iff d2 < thr (reference: max_correspondence_dist_ itself,
 // icp_point_to_point.cpp:70; Open3D: radius^2)
@@ -163,8 +125,6 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
     hit.d2 = thr;
     hit.j = -1;
     hit.px = hit.py = hit.pz = 0.0f;
-    hit.bcell = -1;
-    hit.bslot = 0;
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || g.n == 0) return hit;
     const float gx = (qx - g.org[0]) * g.inv_h, gy = (qy - g.org[1]) * g.inv_h, gz = (qz - g.org[2]) * g.inv_h;
     const int nx = g.dim[0], ny = g.dim[1], nz = g.dim[2];
@@ -176,63 +136,7 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
     const int rcap = max(nx, max(ny, nz));
 
     for (int R = 1; R <= rcap; ++R) {
-        if (R == 1 && g.bkt != nullptr) {
-            // ---- bucket path: own cell, then the needed ones of the 26 neighbours
-            const int c0 = (cz * ny + cy) * nx + cx;
-            {
-                const Bucket b = load_bucket(g, c0);
-                scan_bucket<WINDOW>(g, w, c0, b, qx, qy, qz, hit);
-            }
-            // gaps (metres, >= 0) from the query to the neighbouring slabs on each axis
-            const float fx = gx - (float)cx, fy = gy - (float)cy, fz = gz - (float)cz;
-            const float gxm = fmaxf(fx, 0.0f) * h, gxp = fmaxf(1.0f - fx, 0.0f) * h;
-            const float gym = fmaxf(fy, 0.0f) * h, gyp = fmaxf(1.0f - fy, 0.0f) * h;
-            const float gzm = fmaxf(fz, 0.0f) * h, gzp = fmaxf(1.0f - fz, 0.0f) * h;
-            auto cell_gap2 = [&](int k) -> float {
-                const int dx = nb_off(NB_OXP, k), dy = nb_off(NB_OYP, k), dz = nb_off(NB_OZP, k);
-                const float rx = dx < 0 ? gxm : (dx > 0 ? gxp : 0.0f);
-                const float ry = dy < 0 ? gym : (dy > 0 ? gyp : 0.0f);
-                const float rz = dz < 0 ? gzm : (dz > 0 ? gzp : 0.0f);
-                return (rx * rx + ry * ry + rz * rz) * 0.998f;
-            };
-            auto cell_id = [&](int k) -> int {
-                return ((cz + nb_off(NB_OZP, k)) * ny + (cy + nb_off(NB_OYP, k))) * nx + (cx + nb_off(NB_OXP, k));
-            };
-            uint32_t mask = 0;
-#pragma unroll
-            for (int k = 0; k < 26; ++k) {
-                const int dx = nb_off(NB_OXP, k), dy = nb_off(NB_OYP, k), dz = nb_off(NB_OZP, k);
-                const bool inside = (unsigned)(cx + dx) < (unsigned)nx && (unsigned)(cy + dy) < (unsigned)ny && (unsigned)(cz + dz) < (unsigned)nz;
-                if (inside && cell_gap2(k) < hit.d2) mask |= 1u << k;
-            }
-            int k = -1, cell = 0;
-            Bucket cur;
-            cur.x = cur.y = cur.z = cur.j = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mask) {
-                k = __ffs((int)mask) - 1;
-                mask &= mask - 1;
-                cell = cell_id(k);
-                cur = load_bucket(g, cell);
-            }
-            while (k >= 0) {
-                int k1 = -1, cell1 = 0;
-                Bucket nxt = cur;
-                while (mask) { // next still-needed neighbour: request its line before evaluating this one
-                    const int kk = __ffs((int)mask) - 1;
-                    mask &= mask - 1;
-                    if (cell_gap2(kk) < hit.d2) {
-                        k1 = kk;
-                        cell1 = cell_id(kk);
-                        nxt = load_bucket(g, cell1);
-                        break;
-                    }
-                }
-                if (cell_gap2(k) < hit.d2) scan_bucket<WINDOW>(g, w, cell, cur, qx, qy, qz, hit);
-                k = k1;
-                cell = cell1;
-                cur = nxt;
-            }
-        } else {
+        {
             // ---- CSR path: rows of 2R+1 cells
             const int x0 = max(cx - R, 0), x1 = min(cx + R, nx - 1);
             const int y0 = max(cy - R, 0), y1 = min(cy + R, ny - 1);

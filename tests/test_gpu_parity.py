@@ -389,29 +389,3 @@ def test_gpu_against_golden(api, ctx, synth):
     icp.set_num_iterations(20)
     r = icp.align("p2plane")
     assert_pose_close(synth, r["T64"], g["pl_T"], 1e-9, 1e-9)
-
-
-def test_bucket_path_equals_csr_path(api, ctx, orc, synth, small_world, monkeypatch):
-    """SF_MAP_BUCKETS=1 adds the per-cell 128-byte bucket image of the grid (an alternative
-    ring-1 layout kept for comparison); results must equal the default CSR rows."""
-    m, scan = small_world["map"], small_world["scan"]
-    q = np.concatenate([scan, scan + np.float32(0.4), np.array([[1e6, 0, 0], [-40, -40, 9]], np.float32)])
-    csr = api.Map(ctx, api.Cloud(ctx, m), 0.25)
-    monkeypatch.setenv("SF_MAP_BUCKETS", "1")
-    bkt = api.Map(ctx, api.Cloud(ctx, m), 0.25)
-    monkeypatch.delenv("SF_MAP_BUCKETS")
-    gi0, gd0 = csr.nn(q)
-    gi1, gd1 = bkt.nn(q)
-    oi, od = orc.KdTreeF(m).nn(q)
-    assert np.array_equal(gd0, gd1) and np.array_equal(gd1[np.isfinite(od)], od[np.isfinite(od)])
-    assert (gi0 == gi1).mean() > 0.999
-    for mp in (csr, bkt):
-        mp.estimate_normals(0.25)
-    res = []
-    for mp in (csr, bkt):
-        icp = api.Icp(ctx, 0.5, 20, 0.05, 1e-5)
-        icp.set_target(mp)
-        icp.set_source(scan)
-        res.append(icp.align("p2plane"))
-    assert_pose_close(synth, res[0]["T64"], res[1]["T64"], 1e-9, 1e-10)
-    assert res[0]["n_corr"] == res[1]["n_corr"]
