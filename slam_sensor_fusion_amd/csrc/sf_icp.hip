@@ -39,6 +39,9 @@ struct IcpState {
     float step[12];
     int step_pending;
     int iterations, done, research, n_corr, n_research, flags, converged;
+    // sharded path: pose at which this rank's owned-query list was built, and the rebuild request
+    double T_list[12];
+    int rebuild;
 };
 
 struct IcpParams {
@@ -405,6 +408,8 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
     for (int i = 0; i < 12; ++i) s.step[i] = 0;
     s.step_pending = 0;
     s.iterations = s.done = s.research = s.n_corr = s.n_research = s.flags = s.converged = 0;
+    for (int i = 0; i < 12; ++i) s.T_list[i] = s.T[i];
+    s.rebuild = 1;
     st[b] = s;
 }
 
@@ -416,17 +421,26 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
 // afterwards and goes straight into the wave reduction.
 template <int MODE, bool WINDOW, bool SHARD>
 __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
-                                                int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks)
+                                                int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks,
+                                                const uint32_t *__restrict__ own_list, const uint32_t *__restrict__ own_count)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.y;
     const IcpState *S = st + b;
     if (S->done) return;
-    const int i = blockIdx.x * BLK + threadIdx.x;
+    const int slot = blockIdx.x * BLK + threadIdx.x;
+    // sharded: this rank walks only its list of owned-query candidates (built with a margin and
+    // rebuilt when the pose has moved, k_own_*); the exact slab predicate is still applied per lane
+    const int n_live = SHARD ? (int)own_count[b] : n;
+    if (SHARD && blockIdx.x * BLK >= n_live) { // whole workgroup beyond the list: its slab row must still read as zeros
+        if (threadIdx.x < NREC) partials[((size_t)b * nblocks + blockIdx.x) * REC_STRIDE + threadIdx.x] = 0.0;
+        return;
+    }
     double sx = 0, sy = 0, sz = 0;
     sf::NNHit hit;
     hit.j = -1;
-    if (i < n) {
+    if (slot < n_live) {
+        const int i = SHARD ? (int)own_list[(size_t)b * n + slot] : slot;
         const size_t o = (size_t)b * n + i;
         const double x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
         sx = S->T[0] * x0 + S->T[1] * y0 + S->T[2] * z0 + S->T[3];
@@ -508,6 +522,129 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
         double *dst = partials + ((size_t)b * nblocks + blockIdx.x) * REC_STRIDE;
         dst[c] = ((stage[0][c] + stage[1][c]) + stage[2][c]) + stage[3][c];
     }
+}
+
+// ------------------------------------------------------------------ sharded path: owned-query lists
+// A rank owns the queries whose TRANSFORMED x lies in its slab [xlo, xhi).  Evaluating that per
+// lane over the whole batch leaves 1/N of the lanes of every wave busy (no speed-up); instead
+// each rank keeps, per scan, the list of queries within the slab widened by OWN_MARGIN at the
+// pose T_list, walks only that list, and rebuilds it when any point of the scan's bounding box
+// has moved by more than OWN_MARGIN / 2 since (decided on the device, identically on every
+// rank because every rank holds the same T).  Order-preserving compaction: per-workgroup
+// counts (ballot + popcount), one-workgroup scan per scan, scatter with the mbcnt lane rank.
+constexpr float OWN_MARGIN = 0.5f;
+
+struct ScanBox { float lo[3], hi[3]; };
+
+__device__ __forceinline__ unsigned own_lane_rank(unsigned long long ballot)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0u));
+}
+
+__device__ __forceinline__ bool own_candidate(const IcpState *S, float x0, float y0, float z0, float xlo, float xhi)
+{
+    const float qx = (float)(S->T[0] * (double)x0 + S->T[1] * (double)y0 + S->T[2] * (double)z0 + S->T[3]);
+    return qx >= xlo - OWN_MARGIN && qx < xhi + OWN_MARGIN;
+}
+
+__global__ __launch_bounds__(BLK) void k_own_count(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
+                                                   const IcpState *__restrict__ st, float xlo, float xhi, uint32_t *__restrict__ blk_counts, int nblocks)
+{
+    const int b = blockIdx.y;
+    const IcpState *S = st + b;
+    if (S->done || !S->rebuild) return;
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+        const size_t o = (size_t)b * n + i;
+        keep = own_candidate(S, X0x[o], X0y[o], X0z[o], xlo, xhi);
+    }
+    __shared__ uint32_t wcnt[BLK / 64];
+    const unsigned long long bal = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_counts[(size_t)b * nblocks + blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+// one workgroup per scan: exclusive scan of its block counts in place, total -> own_count[b]
+__global__ __launch_bounds__(1024) void k_own_scan(const IcpState *__restrict__ st, uint32_t *__restrict__ blk_counts, int nblocks, uint32_t *__restrict__ own_count)
+{
+    const int b = blockIdx.x;
+    if (st[b].done || !st[b].rebuild) return;
+    uint32_t *v = blk_counts + (size_t)b * nblocks;
+    __shared__ uint32_t s[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t x = i < nblocks ? v[i] : 0u;
+        s[threadIdx.x] = x;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t t = threadIdx.x >= (unsigned)off ? s[threadIdx.x - off] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = s[threadIdx.x], c0 = carry;
+        if (i < nblocks) v[i] = c0 + incl - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c0 + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) own_count[b] = carry;
+}
+
+__global__ __launch_bounds__(BLK) void k_own_scatter(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
+                                                     const IcpState *__restrict__ st, float xlo, float xhi, const uint32_t *__restrict__ blk_off, int nblocks,
+                                                     uint32_t *__restrict__ own_list)
+{
+    const int b = blockIdx.y;
+    const IcpState *S = st + b;
+    if (S->done || !S->rebuild) return;
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+        const size_t o = (size_t)b * n + i;
+        keep = own_candidate(S, X0x[o], X0y[o], X0z[o], xlo, xhi);
+    }
+    __shared__ uint32_t wcnt[BLK / 64];
+    const unsigned long long bal = __ballot(keep);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) wcnt[wv] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (!keep) return;
+    uint32_t off = blk_off[(size_t)b * nblocks + blockIdx.x];
+    for (int k = 0; k < wv; ++k) off += wcnt[k];
+    own_list[(size_t)b * n + off + own_lane_rank(bal)] = (uint32_t)i;
+}
+
+// after the list was used for the first time: remember the pose it was built at
+__device__ __forceinline__ void own_list_built(IcpState *S)
+{
+    if (S->rebuild) {
+        for (int i = 0; i < 12; ++i) S->T_list[i] = S->T[i];
+        S->rebuild = 0;
+    }
+}
+
+// after a pose update: has any point of the scan's bounding box moved more than OWN_MARGIN / 2
+// since the list was built?  (an affine map of a box moves its corners the most)
+__device__ __forceinline__ void own_check_motion(IcpState *S, const ScanBox &box)
+{
+    double worst = 0.0;
+    for (int c = 0; c < 8; ++c) {
+        const double x = (c & 1) ? box.hi[0] : box.lo[0], y = (c & 2) ? box.hi[1] : box.lo[1], z = (c & 4) ? box.hi[2] : box.lo[2];
+        double d2 = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            const double a = S->T[4 * r] * x + S->T[4 * r + 1] * y + S->T[4 * r + 2] * z + S->T[4 * r + 3];
+            const double o = S->T_list[4 * r] * x + S->T_list[4 * r + 1] * y + S->T_list[4 * r + 2] * z + S->T_list[4 * r + 3];
+            d2 += (a - o) * (a - o);
+        }
+        worst = d2 > worst ? d2 : worst;
+    }
+    if (!(worst < 0.25 * (double)OWN_MARGIN * (double)OWN_MARGIN)) S->rebuild = 1;
 }
 
 // ------------------------------------------------------------------ solves (thread 0 of the scan's workgroup)
@@ -592,7 +729,7 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve(IcpState *__restrict__ st
 
 // multi-GPU split: reduce into the exchange buffer, all-reduce outside, then solve
 template <int MODE>
-__global__ __launch_bounds__(RBLK) void k_reduce_only(const IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, double *__restrict__ xchg)
+__global__ __launch_bounds__(RBLK) void k_reduce_only(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, double *__restrict__ xchg)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x;
@@ -603,10 +740,11 @@ __global__ __launch_bounds__(RBLK) void k_reduce_only(const IcpState *__restrict
     }
     reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, nblocks, rec);
     if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = rec[threadIdx.x];
+    if (threadIdx.x == 0) own_list_built(st + b);
 }
 
 template <int MODE>
-__global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict__ xchg, int n_src, int k, int K, int batch)
+__global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict__ xchg, int n_src, int k, int K, int batch, ScanBox box)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -620,6 +758,7 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
     for (int c = 0; c < NREC; ++c) S->rec[c] = rec[c];
     if (MODE == 1) solve_o3d(S, rec, n_src, k, K);
     else solve_plane(S, rec, n_src, K);
+    if (!S->done) own_check_motion(S, box);
 }
 
 // ------------------------------------------------------------------ REF_CPP mode
@@ -790,6 +929,8 @@ struct sf_icp {
     // sharding
     bool shard = false;
     float xlo = 0, xhi = 0;
+    sf::DevBuf own_list, own_blk, own_count; // sharded path: per-scan owned-query lists
+    ScanBox box{};                           // bounding box of the source batch (finite points)
     int step_k = 0;
     int last_mode = 0;
     // graph
@@ -838,6 +979,9 @@ int icp_set_source_device_aos(sf_icp *icp, const float *d_aos, int64_t n, int ba
         hipLaunchKernelGGL(k_soa_from_aos, dim3(nblk(total)), dim3(256), 0, icp->ctx->stream, d_aos, total, soa(icp->X0, total, 0), soa(icp->X0, total, 1),
                            soa(icp->X0, total, 2));
     SF_HIP(hipGetLastError());
+    sf::MinMaxHost mm; // bounding box of the batch: the sharded path's list-rebuild rule needs it
+    SF_TRY(sf::cloud_minmax(icp->ctx, d_aos, total, &mm));
+    for (int d = 0; d < 3; ++d) { icp->box.lo[d] = mm.mn[d]; icp->box.hi[d] = mm.mx[d]; }
     icp->have_source = true;
     return SF_OK;
 }
@@ -876,7 +1020,7 @@ void prof_collect(sf_icp *icp)
 float o3d_thr(const sf_icp *icp) { return (float)((double)icp->prm.max_corr * (double)icp->prm.max_corr); }
 
 template <int MODE>
-void launch_nn_red(sf_icp *icp)
+void launch_nn_red(sf_icp *icp, bool sharded = false)
 {
     sf_map *m = icp->map;
     const dim3 grid((unsigned)icp->nblocks, (unsigned)icp->batch), blk(BLK);
@@ -889,10 +1033,11 @@ void launch_nn_red(sf_icp *icp)
     ProfScope ps(icp);
     const bool win = m->window.kind != 0;
 #define SF_LAUNCH_NNRED(W, S)                                                                                                                                    \
-    hipLaunchKernelGGL((k_nn_red<MODE, W, S>), grid, blk, 0, s, m->grid, m->window, x, y, z, (int)icp->n, st, thr, icp->xlo, icp->xhi, part, icp->nblocks)
-    if (win && icp->shard) SF_LAUNCH_NNRED(true, true);
+    hipLaunchKernelGGL((k_nn_red<MODE, W, S>), grid, blk, 0, s, m->grid, m->window, x, y, z, (int)icp->n, st, thr, icp->xlo, icp->xhi, part, icp->nblocks, \
+                       icp->own_list.as<uint32_t>(), icp->own_count.as<uint32_t>())
+    if (win && sharded) SF_LAUNCH_NNRED(true, true);
     else if (win) SF_LAUNCH_NNRED(true, false);
-    else if (icp->shard) SF_LAUNCH_NNRED(false, true);
+    else if (sharded) SF_LAUNCH_NNRED(false, true);
     else SF_LAUNCH_NNRED(false, false);
 #undef SF_LAUNCH_NNRED
 }
@@ -1018,7 +1163,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     if (icp->graph_exec) { e = hipGraphExecDestroy(icp->graph_exec); (void)e; }
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
     icp->X0.release(); icp->X.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
-    icp->partials.release(); icp->xchg_own.release();
+    icp->partials.release(); icp->xchg_own.release(); icp->own_list.release(); icp->own_blk.release(); icp->own_count.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
     sf_ctx *ctx = icp->ctx;
@@ -1223,11 +1368,24 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
     if (first) { launch_state_init(icp); icp->step_k = 0; }
     double *x = reinterpret_cast<double *>(sf_icp_exchange_ptr(icp, nullptr));
     hipStream_t s = icp->ctx->stream;
+    if (icp->shard) { // (re)build this rank's owned-query lists where the device asked for it
+        const int64_t total = icp->n * icp->batch;
+        SF_TRY(icp->own_list.reserve(sizeof(uint32_t) * (size_t)std::max<int64_t>(total, 1)));
+        SF_TRY(icp->own_blk.reserve(sizeof(uint32_t) * (size_t)icp->nblocks * (size_t)icp->batch));
+        SF_TRY(icp->own_count.reserve(sizeof(uint32_t) * (size_t)icp->batch));
+        const dim3 grid((unsigned)icp->nblocks, (unsigned)icp->batch);
+        const float *X = soa(icp->X0, total, 0), *Y = soa(icp->X0, total, 1), *Z = soa(icp->X0, total, 2);
+        IcpState *st = icp->state.as<IcpState>();
+        hipLaunchKernelGGL(k_own_count, grid, dim3(BLK), 0, s, X, Y, Z, (int)icp->n, st, icp->xlo, icp->xhi, icp->own_blk.as<uint32_t>(), icp->nblocks);
+        hipLaunchKernelGGL(k_own_scan, dim3((unsigned)icp->batch), dim3(1024), 0, s, st, icp->own_blk.as<uint32_t>(), icp->nblocks, icp->own_count.as<uint32_t>());
+        hipLaunchKernelGGL(k_own_scatter, grid, dim3(BLK), 0, s, X, Y, Z, (int)icp->n, st, icp->xlo, icp->xhi, icp->own_blk.as<uint32_t>(), icp->nblocks,
+                           icp->own_list.as<uint32_t>());
+    }
     if (mode == SF_ICP_O3D_P2P) {
-        launch_nn_red<1>(icp);
+        launch_nn_red<1>(icp, icp->shard);
         hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), icp->nblocks, x);
     } else {
-        launch_nn_red<2>(icp);
+        launch_nn_red<2>(icp, icp->shard);
         hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), icp->nblocks, x);
     }
     SF_HIP(hipGetLastError());
@@ -1242,9 +1400,9 @@ extern "C" int sf_icp_step_end(sf_icp *icp, int mode, int last)
     hipStream_t s = icp->ctx->stream;
     const int K = icp->prm.num_iters;
     if (mode == SF_ICP_O3D_P2P)
-        hipLaunchKernelGGL(k_solve_only<1>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, icp->step_k, K, icp->batch);
+        hipLaunchKernelGGL(k_solve_only<1>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, icp->step_k, K, icp->batch, icp->box);
     else
-        hipLaunchKernelGGL(k_solve_only<2>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, icp->step_k, K, icp->batch);
+        hipLaunchKernelGGL(k_solve_only<2>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, icp->step_k, K, icp->batch, icp->box);
     icp->step_k += 1;
     SF_HIP(hipGetLastError());
     return SF_OK;

@@ -310,17 +310,23 @@ def test_icp_batch_graph_and_determinism(api, ctx, orc, synth, small_world):
             assert np.array_equal(a[k]["T64"], b[k]["T64"]) and a[k]["iterations"] == b[k]["iterations"]
 
 
-def test_sharded_steps_equal_single_shot(api, ctx, orc, synth, small_world):
+@pytest.mark.parametrize("offset", [0.0, 0.45])
+def test_sharded_steps_equal_single_shot(api, ctx, orc, synth, small_world, offset):
     """Two x-slabs on one GPU: summing the two exchange records by hand must reproduce the
-    unsharded registration (the multi-GPU path minus RCCL)."""
+    unsharded registration (the multi-GPU path minus RCCL).  offset = 0.45 m starts far enough
+    for the pose to move by more than the owned-list margin / 2, so the lists are rebuilt on the
+    device in mid-alignment."""
+    import torch
     from slam_sensor_fusion_amd import sharded
     m, scan = small_world["map"], small_world["scan"]
+    init = synth.make_T((offset, 0.0, 0.0), (0, 0, 0))
     edges = sharded.slab_edges(m[:, 0], 2)
     full = api.Map(ctx, api.Cloud(ctx, m), 0.25)
     full.estimate_normals(0.25)
     icp0 = api.Icp(ctx, 0.5, 20, 0.05, 1e-5)
     icp0.set_target(full)
     icp0.set_source(scan)
+    icp0.set_initial_transformation(init)
     ref = icp0.align("p2plane")
     maps, icps = [], []
     for r in range(2):
@@ -330,17 +336,19 @@ def test_sharded_steps_equal_single_shot(api, ctx, orc, synth, small_world):
         icp = api.Icp(ctx, 0.5, 20, 0.05, 1e-5)
         icp.set_target(mp)
         icp.set_source(scan)
+        icp.set_initial_transformation(init)
         icp.set_shard(float(edges[r]), float(edges[r + 1]))
         maps.append(mp)
         icps.append(icp)
-    import torch
     xb = [torch.zeros(32, dtype=torch.float64, device="cuda") for _ in range(2)]
     for icp, x in zip(icps, xb):
         icp.set_exchange_buffer(x.data_ptr(), 256)
+    owned = []
     for k in range(20):
         for icp in icps:
             icp.step_begin("p2plane", first=(k == 0))
         ctx.synchronize()
+        owned.append(float(xb[0][0] + xb[1][0]))
         total = xb[0] + xb[1]                      # what the RCCL all-reduce does across ranks
         xb[0].copy_(total)
         xb[1].copy_(total)
@@ -352,6 +360,7 @@ def test_sharded_steps_equal_single_shot(api, ctx, orc, synth, small_world):
         r = icp.fetch_results()[0]
         assert r["iterations"] == 20 and r["n_corr"] == ref["n_corr"]
         assert_pose_close(synth, r["T64"], ref["T64"], 1e-9, 1e-10)
+    assert owned[-1] == ref["n_corr"]             # every query owned by exactly one slab
 
 
 # ------------------------------------------------------------------ committed golden vectors
