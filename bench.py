@@ -170,6 +170,21 @@ def main():
             lat.align(args.mode)
         single_ms = (time.perf_counter() - tl) / 10 * 1e3
 
+    # ---------------- HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this
+    # process, so the figure comes from the rocprofv3 --pmc passes of this same command committed under
+    # profiles/ (request counts x request sizes, i.e. with the gfx950 FETCH_SIZE x2 correction made
+    # explicit); reported only when the configuration matches the profiled one, otherwise null.
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        c = tj["config"]
+        if (world == 1 and c["batch"] == B and c["scan_points"] == n_scan and c["map_points"] == args.map_points
+                and c["iters"] == args.iters and c["mode"] == args.mode):
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ by request size, separate passes)"
+    except (OSError, KeyError, ValueError):
+        pass
+
     scans_total = B * args.steps
     value = scans_total / elapsed
     ms_per_step = elapsed / args.steps * 1e3
@@ -197,7 +212,8 @@ def main():
                    "hip_graph": not args.no_graph},
         "parity": {"max_translation_err_vs_truth_m": terr, "max_rotation_err_vs_truth_rad": rerr, "ok": bool(ok)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": queries_per_launch * a_nn,
                      "kernel": "k_nn_red", "avg_launch_ms": nn_ms, "launches_timed": n_launch,
                      "algorithmic_bytes_per_query": a_nn, "queries_per_launch": queries_per_launch},
         "setup_s": setup_s,
