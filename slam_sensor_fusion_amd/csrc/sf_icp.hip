@@ -1328,7 +1328,9 @@ extern "C" int sf_icp_align_batch(sf_icp *icp, int mode, sf_icp_result *out)
 
 extern "C" int sf_icp_align(sf_icp *icp, int mode, sf_icp_result *out)
 {
-    SF_CHECK(icp && icp->batch == 1, SF_ERR_STATE, "sf_icp_align needs a single source scan (use sf_icp_align_batch)");
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    SF_CHECK(icp->have_source, SF_ERR_STATE, "no source cloud set");
+    SF_CHECK(icp->batch == 1, SF_ERR_STATE, "sf_icp_align needs a single source scan (use sf_icp_align_batch)");
     return sf_icp_align_batch(icp, mode, out);
 }
 

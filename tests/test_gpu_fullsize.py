@@ -104,3 +104,36 @@ def test_registration_200k_vs_10m(api, ctx, synth):
     r = icp.align("p2plane")
     dt, dr = synth.pose_error(r["T64"], synth.t_true())
     assert r["iterations"] == 20 and r["fitness"] > 0.999 and dt < 2e-4 and dr < 1e-5
+
+
+def test_registration_130k_vs_50m(api, ctx, synth):
+    """Config-5-sized case on one GPU: a 50 M-point map (voxel grid -> 47.6 M points, 223 x 223 x 10 m,
+    ~2 x 10^8 grid cells), normals for every map point, a 130 k-point scan taken from a 60 m
+    neighbourhood (a spinning LiDAR's footprint).  PCL's int32 voxel index does not overflow here
+    (2236 x 2236 x 100 < 2^31); the grid-index cell ids are 32-bit as well."""
+    raw = synth.make_map(50_000_000)
+    c = api.Cloud(ctx, raw)
+    del raw
+    flags = c.voxel_downsample(0.1, "pcl")
+    assert flags == 0
+    ids = c.voxel_out_ids()
+    assert (np.diff(ids.astype(np.int64)) > 0).all()
+    ds = c.download()
+    assert 47.0e6 < len(ds) < 48.0e6
+    mp = api.Map(ctx, c, 0.25)
+    mp.estimate_normals(0.25)
+    near = ds[(np.abs(ds[:, 0] - 40.0) < 30.0) & (np.abs(ds[:, 1] + 25.0) < 30.0)]
+    T = synth.make_T((0.12, 0.06, -0.03), (0.05, -0.02, 0.2))
+    scan, _ = synth.make_scan(near, 130_000, scan_id=4, T=T)
+    icp = api.Icp(ctx, 0.5, 20, 0.05, 1e-5)
+    icp.set_target(mp)
+    icp.set_source(scan)
+    r = icp.align("p2plane")
+    dt, dr = synth.pose_error(r["T64"], T)
+    assert r["iterations"] == 20 and r["fitness"] > 0.999 and dt < 3e-4 and dr < 1e-5
+    # window = the reference's 10 m crop: points outside it must not be matched
+    mp.window_sphere([40.0, -25.0, 0.0], 10.0)
+    assert 0 < mp.window_count() < 0.01 * len(ds)
+    r = icp.align("p2plane")
+    inside = ((scan.astype(np.float64) @ T[:3, :3].T + T[:3, 3] - [40.0, -25.0, 0.0]) ** 2).sum(1) < 9.5 ** 2
+    assert inside.sum() * 0.9 < r["n_corr"] < len(scan) * 0.25
