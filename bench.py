@@ -82,7 +82,7 @@ def main():
     map_ds = cloud.download()
     n_map = len(map_ds)
     max_dist = 0.5
-    normal_radius = args.cell
+    normal_radius = 0.25
     edges = sharded.slab_edges(map_ds[:, 0], world)
     if world > 1:
         keep = sharded.slab_select(map_ds, edges, rank, halo=max_dist + normal_radius + args.cell)

@@ -201,6 +201,15 @@ int sf_icp_align_batch(sf_icp *icp, int mode, sf_icp_result *out /* batch entrie
 int sf_icp_align_batch_async(sf_icp *icp, int mode);
 int sf_icp_fetch_results(sf_icp *icp, sf_icp_result *out);
 int sf_icp_use_graph(sf_icp *icp, int on); /* replay the launch sequence as a hipGraph */
+/* Order in which the points of a scan are walked by O3D_P2P / P2PLANE.  The correspondences and
+ * every per-point term are independent of it; only the rounding of the record sums changes
+ * (deterministically for a given order).  CELL sorts each scan by the map-grid cell of its points
+ * under the initial pose at the start of every alignment (on the device, inside sf_icp_align*), so
+ * that scans in flight share map lines in L2; AUTO = CELL when scans x points >= 1e6. */
+#define SF_ORDER_AUTO 0
+#define SF_ORDER_AS_GIVEN 1
+#define SF_ORDER_CELL 2
+int sf_icp_set_query_order(sf_icp *icp, int order);
 
 /* multi-GPU (map tile-sharded along x with halo): this rank only
  * accumulates queries whose TRANSFORMED x lies in [x_lo, x_hi); per iteration

@@ -20,6 +20,8 @@
 #include "sf_common.hpp"
 #include "sf_nn.hpp"
 
+#include <rocprim/rocprim.hpp>
+
 #include <cfloat>
 #include <cmath>
 #include <vector>
@@ -425,15 +427,23 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
                                                 const uint32_t *__restrict__ own_list, const uint32_t *__restrict__ own_count)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
-    const int b = blockIdx.y;
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in launch order, so
+    // linear id L runs on XCD L % 8.  Chunk c (256 consecutive queries of a scan) of EVERY scan in
+    // the batch goes to XCD c % 8, scans adjacent in time: with cell-ordered queries they share
+    // their map lines in that XCD's L2.  grid.x is padded to a multiple of 8.
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int kk = L >> 3;
+    const int b = kk % (int)gridDim.y;
+    const int bx = (kk / (int)gridDim.y) * 8 + (L & 7);
+    if (bx >= nblocks) return;
     const IcpState *S = st + b;
     if (S->done) return;
-    const int slot = blockIdx.x * BLK + threadIdx.x;
+    const int slot = bx * BLK + threadIdx.x;
     // sharded: this rank walks only its list of owned-query candidates (built with a margin and
     // rebuilt when the pose has moved, k_own_*); the exact slab predicate is still applied per lane
     const int n_live = SHARD ? (int)own_count[b] : n;
-    if (SHARD && blockIdx.x * BLK >= n_live) { // whole workgroup beyond the list: its slab row must still read as zeros
-        if (threadIdx.x < NREC) partials[((size_t)b * nblocks + blockIdx.x) * REC_STRIDE + threadIdx.x] = 0.0;
+    if (SHARD && bx * BLK >= n_live) { // whole workgroup beyond the list: its slab row must still read as zeros
+        if (threadIdx.x < NREC) partials[((size_t)b * nblocks + bx) * REC_STRIDE + threadIdx.x] = 0.0;
         return;
     }
     double sx = 0, sy = 0, sz = 0;
@@ -519,9 +529,49 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
     __syncthreads();
     if (threadIdx.x < NREC) {
         const int c = threadIdx.x;
-        double *dst = partials + ((size_t)b * nblocks + blockIdx.x) * REC_STRIDE;
+        double *dst = partials + ((size_t)b * nblocks + bx) * REC_STRIDE;
         dst[c] = ((stage[0][c] + stage[1][c]) + stage[2][c]) + stage[3][c];
     }
+}
+
+// ------------------------------------------------------------------ query order
+// Queries are independent and every sum has a fixed order, so the order of a scan's points is a
+// free choice (it changes the record sums by rounding only, deterministically).  Ordering each
+// scan by the grid cell of its point under the INITIAL pose makes chunk c of every scan in the
+// batch cover the same stretch of the cell-sorted map; k_nn_red then places all the workgroups of
+// one chunk on one XCD, so a map line is fetched from HBM once per batch instead of once per scan.
+__global__ void k_query_keys(SfGrid g, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n, int64_t total,
+                             const IcpState *__restrict__ st, int shift, uint32_t nkeys, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
+{
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const int b = (int)(o / n);
+    const IcpState *S = st + b;
+    const double x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
+    const float qx = (float)(S->T[0] * x0 + S->T[1] * y0 + S->T[2] * z0 + S->T[3]);
+    const float qy = (float)(S->T[4] * x0 + S->T[5] * y0 + S->T[6] * z0 + S->T[7]);
+    const float qz = (float)(S->T[8] * x0 + S->T[9] * y0 + S->T[10] * z0 + S->T[11]);
+    uint32_t key = nkeys - 1; // non-finite queries go to the end of their scan
+    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) {
+        const int cx = (int)fminf(fmaxf(floorf((qx - g.org[0]) * g.inv_h), 0.0f), (float)(g.dim[0] - 1));
+        const int cy = (int)fminf(fmaxf(floorf((qy - g.org[1]) * g.inv_h), 0.0f), (float)(g.dim[1] - 1));
+        const int cz = (int)fminf(fmaxf(floorf((qz - g.org[2]) * g.inv_h), 0.0f), (float)(g.dim[2] - 1));
+        const uint64_t cell = ((uint64_t)cz * (uint64_t)g.dim[1] + (uint64_t)cy) * (uint64_t)g.dim[0] + (uint64_t)cx;
+        key = (uint32_t)(cell >> shift);
+    }
+    keys[o] = (uint32_t)b * nkeys + key;
+    idx[o] = (uint32_t)o;
+}
+
+__global__ void k_gather_queries(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, const uint32_t *__restrict__ idx,
+                                 int64_t total, float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz)
+{
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const uint32_t j = idx[o];
+    Xx[o] = X0x[j];
+    Xy[o] = X0y[j];
+    Xz[o] = X0z[j];
 }
 
 // ------------------------------------------------------------------ sharded path: owned-query lists
@@ -911,6 +961,9 @@ struct sf_icp {
     int debug = 0;
     // source
     sf::DevBuf X0, X;        // SoA: x[B*n], y[B*n], z[B*n]
+    sf::DevBuf Xq, qkeys, qkeys2, qidx, qidx2; // cell-ordered copy of X0 and the sort's buffers
+    int order = SF_ORDER_AUTO;
+    bool ordered = false;    // this alignment reads Xq
     sf::DevBuf corr;         // int32 [B*n] (REF_CPP)
     int64_t n = 0;           // points per scan
     int batch = 0;
@@ -936,7 +989,7 @@ struct sf_icp {
     // graph
     bool use_graph = false;
     hipGraphExec_t graph_exec = nullptr;
-    int graph_mode = -1, graph_iters = -1, graph_batch = -1, graph_window = -1;
+    int graph_mode = -1, graph_iters = -1, graph_batch = -1, graph_window = -1, graph_ordered = -1;
     int64_t graph_n = -1;
     const void *graph_map = nullptr;
     // profiling
@@ -950,6 +1003,51 @@ struct sf_icp {
 namespace {
 
 float *soa(sf::DevBuf &b, int64_t total, int axis) { return b.as<float>() + (size_t)axis * (size_t)total; }
+// the query arrays this alignment walks: the cell-ordered copy or the scans as given
+const float *src(sf_icp *icp, int axis) { return soa(icp->ordered ? icp->Xq : icp->X0, icp->n * icp->batch, axis); }
+
+// AUTO orders when there is enough work for the order to pay for the sort (measured: it does from
+// a few scans in flight; one 200 k-point scan gains less than the sort costs)
+constexpr int64_t ORDER_AUTO_MIN_QUERIES = 1000000;
+
+int order_queries(sf_icp *icp, int mode)
+{
+    const int64_t total = icp->n * icp->batch;
+    const bool want = icp->order == SF_ORDER_CELL || (icp->order == SF_ORDER_AUTO && total >= ORDER_AUTO_MIN_QUERIES);
+    icp->ordered = false;
+    if (!want || mode == SF_ICP_REF_CPP || total == 0 || icp->map->grid.n == 0) return SF_OK;
+    const SfGrid &g = icp->map->grid;
+    const uint64_t ncell = (uint64_t)g.dim[0] * (uint64_t)g.dim[1] * (uint64_t)g.dim[2];
+    int bbits = 0, cbits = 0;
+    while ((1u << bbits) < (unsigned)icp->batch) ++bbits;
+    while (cbits < 63 && (1ull << cbits) < ncell) ++cbits;
+    const int shift = std::max(0, cbits + bbits - 24); // 24 key bits: finer order gains nothing, coarser loses (measured 12..30)
+    const uint32_t nkeys = (uint32_t)((ncell - 1) >> shift) + 1;
+    int bits = 0;
+    while (bits < 32 && (1ull << bits) < (uint64_t)nkeys * (uint64_t)icp->batch) ++bits;
+    const size_t nb = sizeof(uint32_t) * (size_t)total;
+    SF_TRY(icp->Xq.reserve(sizeof(float) * 3 * (size_t)total));
+    SF_TRY(icp->qkeys.reserve(nb));
+    SF_TRY(icp->qkeys2.reserve(nb));
+    SF_TRY(icp->qidx.reserve(nb));
+    SF_TRY(icp->qidx2.reserve(nb));
+    hipStream_t s = icp->ctx->stream;
+    hipLaunchKernelGGL(k_query_keys, dim3(nblk(total)), dim3(256), 0, s, g, soa(icp->X0, total, 0), soa(icp->X0, total, 1), soa(icp->X0, total, 2), (int)icp->n, total,
+                       icp->state.as<IcpState>(), shift, nkeys, icp->qkeys.as<uint32_t>(), icp->qidx.as<uint32_t>());
+    size_t tmp = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, icp->qkeys.as<uint32_t>(), icp->qkeys2.as<uint32_t>(), icp->qidx.as<uint32_t>(), icp->qidx2.as<uint32_t>(),
+                                             (size_t)total, 0, bits, s);
+    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs(size): %s", hipGetErrorString(e));
+    SF_TRY(sf::ensure_scratch(icp->ctx, tmp));
+    e = rocprim::radix_sort_pairs(icp->ctx->scratch.p, tmp, icp->qkeys.as<uint32_t>(), icp->qkeys2.as<uint32_t>(), icp->qidx.as<uint32_t>(), icp->qidx2.as<uint32_t>(),
+                                  (size_t)total, 0, bits, s);
+    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_gather_queries, dim3(nblk(total)), dim3(256), 0, s, soa(icp->X0, total, 0), soa(icp->X0, total, 1), soa(icp->X0, total, 2),
+                       icp->qidx2.as<uint32_t>(), total, soa(icp->Xq, total, 0), soa(icp->Xq, total, 1), soa(icp->Xq, total, 2));
+    SF_HIP(hipGetLastError());
+    icp->ordered = true;
+    return SF_OK;
+}
 
 int icp_alloc(sf_icp *icp, int64_t n, int batch)
 {
@@ -1023,9 +1121,8 @@ template <int MODE>
 void launch_nn_red(sf_icp *icp, bool sharded = false)
 {
     sf_map *m = icp->map;
-    const dim3 grid((unsigned)icp->nblocks, (unsigned)icp->batch), blk(BLK);
-    const int64_t total = icp->n * icp->batch;
-    const float *x = soa(icp->X0, total, 0), *y = soa(icp->X0, total, 1), *z = soa(icp->X0, total, 2);
+    const dim3 grid((unsigned)((icp->nblocks + 7) & ~7), (unsigned)icp->batch), blk(BLK); // see the XCD mapping in k_nn_red
+    const float *x = src(icp, 0), *y = src(icp, 1), *z = src(icp, 2);
     const IcpState *st = icp->state.as<IcpState>();
     double *part = icp->partials.as<double>();
     const float thr = o3d_thr(icp);
@@ -1162,7 +1259,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     (void)e;
     if (icp->graph_exec) { e = hipGraphExecDestroy(icp->graph_exec); (void)e; }
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
-    icp->X0.release(); icp->X.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
+    icp->X0.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
     icp->partials.release(); icp->xchg_own.release(); icp->own_list.release(); icp->own_blk.release(); icp->own_count.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
@@ -1258,6 +1355,14 @@ extern "C" int sf_icp_set_target(sf_icp *icp, const float *xyz, int64_t n)
     return SF_OK;
 }
 
+extern "C" int sf_icp_set_query_order(sf_icp *icp, int order)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    SF_CHECK(order >= SF_ORDER_AUTO && order <= SF_ORDER_CELL, SF_ERR_INVALID, "unknown query order %d", order);
+    icp->order = order;
+    return SF_OK;
+}
+
 extern "C" int sf_icp_use_graph(sf_icp *icp, int on)
 {
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
@@ -1272,10 +1377,11 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     hipStream_t s = icp->ctx->stream;
     icp->last_mode = mode;
     launch_state_init(icp);
+    SF_TRY(order_queries(icp, mode)); // plain launches ahead of the (replayed) iteration graph
     if (icp->use_graph && !icp->profiling) {
         const bool hit = icp->graph_exec && icp->graph_mode == mode && icp->graph_iters == icp->prm.num_iters && icp->graph_batch == icp->batch &&
                          icp->graph_n == icp->n && icp->graph_map == (const void *)icp->map->grid.pts && icp->graph_window == icp->map->window.kind &&
-                         icp->map->window.kind == 0 && !icp->shard;
+                         icp->map->window.kind == 0 && !icp->shard && icp->graph_ordered == (int)icp->ordered;
         if (!hit) {
             if (icp->graph_exec) { hipError_t e = hipGraphExecDestroy(icp->graph_exec); (void)e; icp->graph_exec = nullptr; }
             if (mode == SF_ICP_REF_CPP) { // buffers must exist before capture
@@ -1294,7 +1400,7 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
             (void)e2;
             SF_CHECK(e == hipSuccess, SF_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
             icp->graph_mode = mode; icp->graph_iters = icp->prm.num_iters; icp->graph_batch = icp->batch; icp->graph_n = icp->n;
-            icp->graph_map = (const void *)icp->map->grid.pts; icp->graph_window = icp->map->window.kind;
+            icp->graph_map = (const void *)icp->map->grid.pts; icp->graph_window = icp->map->window.kind; icp->graph_ordered = (int)icp->ordered;
         }
         SF_HIP(hipGraphLaunch(icp->graph_exec, s));
         return SF_OK;
@@ -1367,7 +1473,7 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
     SF_CHECK(mode != SF_ICP_REF_CPP, SF_ERR_INVALID, "stepping supports O3D_P2P and P2PLANE");
     SF_HIP(hipSetDevice(icp->ctx->device));
     icp->last_mode = mode;
-    if (first) { launch_state_init(icp); icp->step_k = 0; }
+    if (first) { launch_state_init(icp); SF_TRY(order_queries(icp, mode)); icp->step_k = 0; }
     double *x = reinterpret_cast<double *>(sf_icp_exchange_ptr(icp, nullptr));
     hipStream_t s = icp->ctx->stream;
     if (icp->shard) { // (re)build this rank's owned-query lists where the device asked for it
@@ -1376,7 +1482,7 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
         SF_TRY(icp->own_blk.reserve(sizeof(uint32_t) * (size_t)icp->nblocks * (size_t)icp->batch));
         SF_TRY(icp->own_count.reserve(sizeof(uint32_t) * (size_t)icp->batch));
         const dim3 grid((unsigned)icp->nblocks, (unsigned)icp->batch);
-        const float *X = soa(icp->X0, total, 0), *Y = soa(icp->X0, total, 1), *Z = soa(icp->X0, total, 2);
+        const float *X = src(icp, 0), *Y = src(icp, 1), *Z = src(icp, 2);
         IcpState *st = icp->state.as<IcpState>();
         hipLaunchKernelGGL(k_own_count, grid, dim3(BLK), 0, s, X, Y, Z, (int)icp->n, st, icp->xlo, icp->xhi, icp->own_blk.as<uint32_t>(), icp->nblocks);
         hipLaunchKernelGGL(k_own_scan, dim3((unsigned)icp->batch), dim3(1024), 0, s, st, icp->own_blk.as<uint32_t>(), icp->nblocks, icp->own_count.as<uint32_t>());

@@ -7,7 +7,7 @@ for rep in 1 2; do
 for lib in "$@"; do
   cp $lib $L
   for B in $BS; do
-    python bench.py --steps 8 --warmup 2 --batch $B --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], 'B', d['config']['scans_in_flight'], 'scans/s', round(d['value'],1), 'nn_us', round(d['roofline']['avg_launch_ms']*1e3,1), d['parity']['ok'])" $(basename $lib)
+    python bench.py $BENCH_EXTRA --steps 8 --warmup 2 --batch $B --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], 'B', d['config']['scans_in_flight'], 'scans/s', round(d['value'],1), 'nn_us', round(d['roofline']['avg_launch_ms']*1e3,1), d['parity']['ok'])" $(basename $lib)
   done
 done
 done
