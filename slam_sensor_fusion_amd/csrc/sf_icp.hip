@@ -428,13 +428,15 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in launch order, so
-    // linear id L runs on XCD L % 8.  Chunk c (256 consecutive queries of a scan) of EVERY scan in
-    // the batch goes to XCD c % 8, scans adjacent in time: with cell-ordered queries they share
-    // their map lines in that XCD's L2.  grid.x is padded to a multiple of 8.
+    // linear id L runs on XCD L % 8.  Each XCD sweeps its own CONTIGUOUS eighth of the chunks
+    // (chunk = 256 consecutive queries of a scan), all scans of the batch adjacent in time: with
+    // cell-ordered queries, chunk c of every scan covers about the same stretch of the map (to
+    // within a chunk or so), so neighbouring chunks must meet in the same L2.  grid.x is padded
+    // to a multiple of 8.
     const int L = blockIdx.y * gridDim.x + blockIdx.x;
     const int kk = L >> 3;
     const int b = kk % (int)gridDim.y;
-    const int bx = (kk / (int)gridDim.y) * 8 + (L & 7);
+    const int bx = (L & 7) * ((int)gridDim.x >> 3) + kk / (int)gridDim.y;
     if (bx >= nblocks) return;
     const IcpState *S = st + b;
     if (S->done) return;
@@ -447,8 +449,8 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
         return;
     }
     double sx = 0, sy = 0, sz = 0;
-    sf::NNHit hit;
-    hit.j = -1;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    bool valid = false;
     if (slot < n_live) {
         const int i = SHARD ? (int)own_list[(size_t)b * n + slot] : slot;
         const size_t o = (size_t)b * n + i;
@@ -456,9 +458,12 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
         sx = S->T[0] * x0 + S->T[1] * y0 + S->T[2] * z0 + S->T[3];
         sy = S->T[4] * x0 + S->T[5] * y0 + S->T[6] * z0 + S->T[7];
         sz = S->T[8] * x0 + S->T[9] * y0 + S->T[10] * z0 + S->T[11];
-        const float qx = (float)sx, qy = (float)sy, qz = (float)sz;
-        if (!SHARD || (qx >= xlo && qx < xhi)) hit = sf::nn_search<WINDOW>(g, w, qx, qy, qz, thr);
+        qx = (float)sx; qy = (float)sy; qz = (float)sz;
+        valid = !SHARD || (qx >= xlo && qx < xhi);
     }
+    // every lane takes part in the search (lanes without a query still execute other lanes' tasks)
+    __shared__ sf::WaveNN nn_ws[BLK / 64];
+    const sf::NNHit hit = sf::nn_search_wave<WINDOW>(g, w, valid, qx, qy, qz, thr, &nn_ws[threadIdx.x >> 6]);
     // contribution of this lane's pair, reduced over the wave in two halves of 16 values
     // (keeps the live registers low enough for 4+ waves per SIMD), staged per wave in LDS
     __shared__ double stage[BLK / 64][32];

@@ -118,14 +118,10 @@ __device__ __forceinline__ float cell_gap(float gc, int c, int cq)
 
 // thr: candidates are accepted iff d2 < thr (reference: max_correspondence_dist_ itself,
 // icp_point_to_point.cpp:70; Open3D: radius^2)
+// rings R_first, R_first + 1, ... around the query's cell until the exactness test holds
 template <bool WINDOW>
-__device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, float qx, float qy, float qz, float thr)
+__device__ __forceinline__ void nn_rings(const SfGrid &g, const SfWindow &w, float qx, float qy, float qz, int R_first, NNHit &hit)
 {
-    NNHit hit;
-    hit.d2 = thr;
-    hit.j = -1;
-    hit.px = hit.py = hit.pz = 0.0f;
-    if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || g.n == 0) return hit;
     const float gx = (qx - g.org[0]) * g.inv_h, gy = (qy - g.org[1]) * g.inv_h, gz = (qz - g.org[2]) * g.inv_h;
     const int nx = g.dim[0], ny = g.dim[1], nz = g.dim[2];
     // clamp in float first: a far-away query must not overflow the int conversion
@@ -135,55 +131,12 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
     const float h = g.h;
     const int rcap = max(nx, max(ny, nz));
 
-    for (int R = 1; R <= rcap; ++R) {
+    for (int R = R_first; R <= rcap; ++R) {
         {
             // ---- CSR path: rows of 2R+1 cells
             const int x0 = max(cx - R, 0), x1 = min(cx + R, nx - 1);
             const int y0 = max(cy - R, 0), y1 = min(cy + R, ny - 1);
             const int z0 = max(cz - R, 0), z1 = min(cz + R, nz - 1);
-#ifndef SF_NN_R1
-#define SF_NN_R1 2
-#endif
-#if SF_NN_R1 == 0
-            if (R == 1) { // simplest: centre row, then the 8 others in a uniform loop
-                const size_t row0 = ((size_t)cz * ny + cy) * nx;
-                scan_range<WINDOW>(g, w, g.cell_start[row0 + x0], g.cell_start[row0 + x1 + 1], qx, qy, qz, hit);
-                for (int z = z0; z <= z1; ++z) {
-                    const float rz = cell_gap(gz, z, cz) * h;
-                    for (int y = y0; y <= y1; ++y) {
-                        if (y == cy && z == cz) continue;
-                        const float ry = cell_gap(gy, y, cy) * h;
-                        if ((ry * ry + rz * rz) * 0.998f >= hit.d2) continue;
-                        const size_t row = ((size_t)z * ny + y) * nx;
-                        scan_range<WINDOW>(g, w, g.cell_start[row + x0], g.cell_start[row + x1 + 1], qx, qy, qz, hit);
-                    }
-                }
-#elif SF_NN_R1 == 1
-            if (R == 1) { // centre row, then the bounds of every surviving row in one batch
-                const size_t row0 = ((size_t)cz * ny + cy) * nx;
-                scan_range<WINDOW>(g, w, g.cell_start[row0 + x0], g.cell_start[row0 + x1 + 1], qx, qy, qz, hit);
-                const int oy[8] = {-1, 1, 0, 0, -1, 1, -1, 1};
-                const int oz[8] = {0, 0, -1, 1, -1, -1, 1, 1};
-                uint32_t ra[8], rb[8];
-                float gap2[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int y = cy + oy[k], z = cz + oz[k];
-                    const bool inside = y >= 0 && y < ny && z >= 0 && z < nz;
-                    const float ry = cell_gap(gy, y, cy) * h, rz = cell_gap(gz, z, cz) * h;
-                    gap2[k] = inside ? (ry * ry + rz * rz) * 0.998f : 3.0e38f;
-                    ra[k] = 0;
-                    rb[k] = 0;
-                    if (gap2[k] < hit.d2) {
-                        const size_t row = ((size_t)z * ny + y) * nx;
-                        ra[k] = g.cell_start[row + x0];
-                        rb[k] = g.cell_start[row + x1 + 1];
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (gap2[k] < hit.d2) scan_range<WINDOW>(g, w, ra[k], rb[k], qx, qy, qz, hit);
-#else
             if (R == 1) {
                 // Ring 1 on the CSR rows.  Per query: one 16-byte look-up gives the bounds of the
                 // three cells of a row; the own cell is scanned first, the x neighbours and the
@@ -247,7 +200,6 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
                     k = k1;
                     cur = nxt;
                 }
-#endif
             } else {
                 for (int z = z0; z <= z1; ++z) {
                     const float rz = cell_gap(gz, z, cz) * h;
@@ -272,6 +224,175 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
         if (m >= 3.0e38f) break; // whole grid scanned
         const float mm = fmaxf(m, 0.0f) * 0.999f;
         if (hit.d2 <= mm * mm) break;
+    }
+}
+
+template <bool WINDOW>
+__device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, float qx, float qy, float qz, float thr)
+{
+    NNHit hit;
+    hit.d2 = thr;
+    hit.j = -1;
+    hit.px = hit.py = hit.pz = 0.0f;
+    if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || g.n == 0) return hit;
+    nn_rings<WINDOW>(g, w, qx, qy, qz, 1, hit);
+    return hit;
+}
+
+// ------------------------------------------------------------------ wave-cooperative search
+// Measured (pass counters, 200 k-point scans vs the 10 M-point map): after every lane has scanned
+// its query's own cell (one step with all 64 lanes busy), the per-lane walk above spends ~10 more
+// wave-level steps on the x neighbours / neighbouring rows that still survive pruning, with ~6 of
+// 64 lanes active in each -- in total fewer than 64 lane-steps of real work.  Here the surviving
+// (query, range) TASKS of the whole wave go into an LDS queue and are dealt out one per lane, so
+// that work takes one or two full steps.  A task scans one contiguous candidate range:
+//   t = 0, 1   the left / right x neighbour of the own cell
+//   t = 2 + k  neighbouring row k (own-x cell plus the x neighbours whose gap is still below the best)
+// and lowers its owner's packed (d2, j) in LDS with ds_min_u64.  The result is the lexicographic
+// minimum of (d2, j) over everything visited; pruning only ever skips ranges that cannot hold a
+// candidate as good as the current best (0.2 % margin), and a task reports ties with the best it
+// started from, so the result does not depend on the order in which lanes finish.
+struct WaveNN {
+    unsigned long long best[64]; // (float bits of d2) << 32 | j; j = 0xffffffff: none
+    float4 q[64];
+    uint16_t task[64 * 10];      // owner lane << 4 | t, grouped by t
+};
+
+__device__ __forceinline__ unsigned long long pack_hit(float d2, int j) { return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)j; }
+
+struct QueryGeo {
+    int cx, cy, cz;
+    float gxm2, gxp2;          // (gap to the left / right x neighbour)^2, 3e38 at the grid border
+    float gym, gyp, gzm, gzp;  // gaps to the neighbouring rows
+};
+
+__device__ __forceinline__ QueryGeo query_geo(const SfGrid &g, float qx, float qy, float qz)
+{
+    QueryGeo G;
+    const float gx = (qx - g.org[0]) * g.inv_h, gy = (qy - g.org[1]) * g.inv_h, gz = (qz - g.org[2]) * g.inv_h;
+    G.cx = (int)fminf(fmaxf(floorf(gx), 0.0f), (float)(g.dim[0] - 1));
+    G.cy = (int)fminf(fmaxf(floorf(gy), 0.0f), (float)(g.dim[1] - 1));
+    G.cz = (int)fminf(fmaxf(floorf(gz), 0.0f), (float)(g.dim[2] - 1));
+    const float h = g.h;
+    const float fx = gx - (float)G.cx, fy = gy - (float)G.cy, fz = gz - (float)G.cz;
+    const float gxm = fmaxf(fx, 0.0f) * h, gxp = fmaxf(1.0f - fx, 0.0f) * h;
+    G.gxm2 = G.cx > 0 ? gxm * gxm : 3.0e38f;
+    G.gxp2 = G.cx < g.dim[0] - 1 ? gxp * gxp : 3.0e38f;
+    G.gym = fmaxf(fy, 0.0f) * h;
+    G.gyp = fmaxf(1.0f - fy, 0.0f) * h;
+    G.gzm = fmaxf(fz, 0.0f) * h;
+    G.gzp = fmaxf(1.0f - fz, 0.0f) * h;
+    return G;
+}
+
+//   k      0   1   2   3   4   5   6   7
+//   dy    -1  +1   0   0  -1  +1  -1  +1
+//   dz     0   0  -1  +1  -1  -1  +1  +1
+__device__ __forceinline__ int row_dy(int k) { return (int)((0x8858u >> (2 * k)) & 3u) - 1; } // dy + 1, two bits per k
+__device__ __forceinline__ int row_dz(int k) { return (int)((0xa085u >> (2 * k)) & 3u) - 1; }
+
+__device__ __forceinline__ float row_gap2(const QueryGeo &G, int k)
+{
+    const int dy = row_dy(k), dz = row_dz(k);
+    const float ry = dy < 0 ? G.gym : (dy > 0 ? G.gyp : 0.0f);
+    const float rz = dz < 0 ? G.gzm : (dz > 0 ? G.gzp : 0.0f);
+    return ry * ry + rz * rz;
+}
+
+// every lane of the wave must call this (lanes without a query pass valid = false: they still work)
+template <bool WINDOW>
+__device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow &w, bool valid, float qx, float qy, float qz, float thr, WaveNN *ws)
+{
+    const int lane = (int)__lane_id();
+    const int nx = g.dim[0], ny = g.dim[1], nz = g.dim[2];
+    NNHit hit;
+    hit.d2 = thr;
+    hit.j = -1;
+    hit.px = hit.py = hit.pz = 0.0f;
+    valid = valid && isfinite(qx) && isfinite(qy) && isfinite(qz) && g.n > 0;
+    uint32_t mask = 0;
+    if (valid) {
+        const QueryGeo G = query_geo(g, qx, qy, qz);
+        const RowBounds rb0 = load_row_bounds(g, ((size_t)G.cz * ny + G.cy) * nx + G.cx);
+        scan_range<WINDOW>(g, w, rb0.s1, rb0.s2, qx, qy, qz, hit);
+        if (G.gxm2 * 0.998f < hit.d2 && rb0.s0 < rb0.s1) mask |= 1u;
+        if (G.gxp2 * 0.998f < hit.d2 && rb0.s2 < rb0.s3) mask |= 2u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool inside = (unsigned)(G.cy + row_dy(k)) < (unsigned)ny && (unsigned)(G.cz + row_dz(k)) < (unsigned)nz;
+            if (inside && row_gap2(G, k) * 0.998f < hit.d2) mask |= 4u << k;
+        }
+    }
+    ws->best[lane] = pack_hit(hit.d2, hit.j);
+    ws->q[lane] = make_float4(qx, qy, qz, 0.0f);
+    int total = 0;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+        const bool has = (mask >> t) & 1u;
+        const unsigned long long bal = __ballot(has);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (has) ws->task[total + rank] = (uint16_t)((lane << 4) | t);
+        total += __popcll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 0; i0 < total; i0 += 64) {
+        const int idx = i0 + lane;
+        if (idx < total) {
+            const uint32_t e = ws->task[idx];
+            const int owner = (int)(e >> 4), t = (int)(e & 15u);
+            const float4 Q = ws->q[owner];
+            const QueryGeo G = query_geo(g, Q.x, Q.y, Q.z);
+            const float cur = __uint_as_float((uint32_t)(__atomic_load_n(&ws->best[owner], __ATOMIC_RELAXED) >> 32));
+            const float g2 = t < 2 ? (t == 0 ? G.gxm2 : G.gxp2) : row_gap2(G, t - 2);
+            if (g2 * 0.998f < cur) {
+                const int dy = t < 2 ? 0 : row_dy(t - 2), dz = t < 2 ? 0 : row_dz(t - 2);
+                const RowBounds rb = load_row_bounds(g, ((size_t)(G.cz + dz) * ny + (G.cy + dy)) * nx + G.cx);
+                uint32_t a, b;
+                if (t < 2) {
+                    a = t == 0 ? rb.s0 : rb.s2;
+                    b = t == 0 ? rb.s1 : rb.s3;
+                } else {
+                    a = (g2 + G.gxm2) * 0.998f < cur ? rb.s0 : rb.s1;
+                    b = (g2 + G.gxp2) * 0.998f < cur ? rb.s3 : rb.s2;
+                }
+                NNHit h;
+                // ties with the best this task started from are reported too (the packed minimum
+                // settles them by index), but never a candidate at the acceptance threshold itself
+                h.d2 = cur < thr ? __uint_as_float(__float_as_uint(cur) + 1u) : thr;
+                h.j = -1;
+                h.px = h.py = h.pz = 0.0f;
+                scan_range<WINDOW>(g, w, a, b, Q.x, Q.y, Q.z, h);
+                if (h.j >= 0) atomicMin(&ws->best[owner], pack_hit(h.d2, h.j));
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+        const unsigned long long m = ws->best[lane];
+        const int j = (int)(uint32_t)m;
+        if (j != hit.j) { // a task found something better: fetch the winner's coordinates
+            const float4 p = g.pts[j];
+            hit.d2 = __uint_as_float((uint32_t)(m >> 32));
+            hit.j = j;
+            hit.px = p.x; hit.py = p.y; hit.pz = p.z;
+        }
+        // exactness of ring 1 (same test as nn_rings); otherwise continue with ring 2 per lane (rare)
+        const float gx = (qx - g.org[0]) * g.inv_h, gy = (qy - g.org[1]) * g.inv_h, gz = (qz - g.org[2]) * g.inv_h;
+        const int cx = (int)fminf(fmaxf(floorf(gx), 0.0f), (float)(nx - 1));
+        const int cy = (int)fminf(fmaxf(floorf(gy), 0.0f), (float)(ny - 1));
+        const int cz = (int)fminf(fmaxf(floorf(gz), 0.0f), (float)(nz - 1));
+        const float h = g.h;
+        float mface = 3.0e38f;
+        if (cx - 1 > 0) mface = fminf(mface, (gx - (float)(cx - 1)) * h);
+        if (cx + 1 < nx - 1) mface = fminf(mface, ((float)(cx + 2) - gx) * h);
+        if (cy - 1 > 0) mface = fminf(mface, (gy - (float)(cy - 1)) * h);
+        if (cy + 1 < ny - 1) mface = fminf(mface, ((float)(cy + 2) - gy) * h);
+        if (cz - 1 > 0) mface = fminf(mface, (gz - (float)(cz - 1)) * h);
+        if (cz + 1 < nz - 1) mface = fminf(mface, ((float)(cz + 2) - gz) * h);
+        const float mm = fmaxf(mface, 0.0f) * 0.999f;
+        if (mface < 3.0e38f && !(hit.d2 <= mm * mm)) nn_rings<WINDOW>(g, w, qx, qy, qz, 2, hit);
     }
     return hit;
 }
