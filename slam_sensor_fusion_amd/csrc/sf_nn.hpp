@@ -72,21 +72,26 @@ __device__ __forceinline__ void consider(const SfWindow &w, float px, float py, 
     }
 }
 
-// CSR candidates [a, b), four independent 16-byte loads in flight per step
+// candidates [j, min(j + 4, b)) of a non-empty CSR range: four independent 16-byte loads.  All four
+// are issued unconditionally (indices clamped into the range) so they are in flight together: a
+// predicated load per candidate costs a round trip each (measured)
+template <bool WINDOW>
+__device__ __forceinline__ void scan4(const SfGrid &g, const SfWindow &w, uint32_t j, uint32_t b, float qx, float qy, float qz, NNHit &hit)
+{
+    const uint32_t last = b - 1;
+    const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
+    const float4 p0 = g.pts[j], p1 = g.pts[j1], p2 = g.pts[j2], p3 = g.pts[j3];
+    consider<WINDOW>(w, p0.x, p0.y, p0.z, (int)j, true, qx, qy, qz, hit);
+    consider<WINDOW>(w, p1.x, p1.y, p1.z, (int)j1, j + 1 < b, qx, qy, qz, hit);
+    consider<WINDOW>(w, p2.x, p2.y, p2.z, (int)j2, j + 2 < b, qx, qy, qz, hit);
+    consider<WINDOW>(w, p3.x, p3.y, p3.z, (int)j3, j + 3 < b, qx, qy, qz, hit);
+}
+
+// CSR candidates [a, b)
 template <bool WINDOW>
 __device__ __forceinline__ void scan_range(const SfGrid &g, const SfWindow &w, uint32_t a, uint32_t b, float qx, float qy, float qz, NNHit &hit)
 {
-    for (uint32_t j = a; j < b; j += 4) {
-        // all four loads are issued unconditionally (indices clamped into the range) so they are
-        // in flight together: a predicated load per candidate costs a round trip each (measured)
-        const uint32_t last = b - 1;
-        const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
-        const float4 p0 = g.pts[j], p1 = g.pts[j1], p2 = g.pts[j2], p3 = g.pts[j3];
-        consider<WINDOW>(w, p0.x, p0.y, p0.z, (int)j, true, qx, qy, qz, hit);
-        consider<WINDOW>(w, p1.x, p1.y, p1.z, (int)j1, j + 1 < b, qx, qy, qz, hit);
-        consider<WINDOW>(w, p2.x, p2.y, p2.z, (int)j2, j + 2 < b, qx, qy, qz, hit);
-        consider<WINDOW>(w, p3.x, p3.y, p3.z, (int)j3, j + 3 < b, qx, qy, qz, hit);
-    }
+    for (uint32_t j = a; j < b; j += 4) scan4<WINDOW>(g, w, j, b, qx, qy, qz, hit);
 }
 
 // cell_start[c-1 .. c+2] in ONE 16-byte load (the table carries one pad entry in front, so
@@ -248,6 +253,7 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
 // that work takes one or two full steps.  A task scans one contiguous candidate range:
 //   t = 0, 1   the left / right x neighbour of the own cell
 //   t = 2 + k  neighbouring row k (own-x cell plus the x neighbours whose gap is still below the best)
+//   t = 10     what is left of an own cell that holds more than four points
 // and lowers its owner's packed (d2, j) in LDS with ds_min_u64.  The result is the lexicographic
 // minimum of (d2, j) over everything visited; pruning only ever skips ranges that cannot hold a
 // candidate as good as the current best (0.2 % margin), and a task reports ties with the best it
@@ -255,7 +261,8 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
 struct WaveNN {
     unsigned long long best[64]; // (float bits of d2) << 32 | j; j = 0xffffffff: none
     float4 q[64];
-    uint16_t task[64 * 10];      // owner lane << 4 | t, grouped by t
+    RowBounds rb0[64];           // bounds of the own cell and its x neighbours (tasks 0, 1, 10)
+    uint16_t task[64 * 11];      // owner lane << 4 | t, grouped by t
 };
 
 __device__ __forceinline__ unsigned long long pack_hit(float d2, int j) { return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)j; }
@@ -314,7 +321,9 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
     if (valid) {
         const QueryGeo G = query_geo(g, qx, qy, qz);
         const RowBounds rb0 = load_row_bounds(g, ((size_t)G.cz * ny + G.cy) * nx + G.cx);
-        scan_range<WINDOW>(g, w, rb0.s1, rb0.s2, qx, qy, qz, hit);
+        ws->rb0[lane] = rb0;
+        if (rb0.s1 < rb0.s2) scan4<WINDOW>(g, w, rb0.s1, rb0.s2, qx, qy, qz, hit);
+        if (rb0.s1 + 4 < rb0.s2 && hit.d2 > 0.0f) mask |= 1u << 10;
         if (G.gxm2 * 0.998f < hit.d2 && rb0.s0 < rb0.s1) mask |= 1u;
         if (G.gxp2 * 0.998f < hit.d2 && rb0.s2 < rb0.s3) mask |= 2u;
 #pragma unroll
@@ -327,7 +336,7 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
     ws->q[lane] = make_float4(qx, qy, qz, 0.0f);
     int total = 0;
 #pragma unroll
-    for (int t = 0; t < 10; ++t) {
+    for (int t = 0; t < 11; ++t) {
         const bool has = (mask >> t) & 1u;
         const unsigned long long bal = __ballot(has);
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
@@ -344,15 +353,16 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
             const float4 Q = ws->q[owner];
             const QueryGeo G = query_geo(g, Q.x, Q.y, Q.z);
             const float cur = __uint_as_float((uint32_t)(__atomic_load_n(&ws->best[owner], __ATOMIC_RELAXED) >> 32));
-            const float g2 = t < 2 ? (t == 0 ? G.gxm2 : G.gxp2) : row_gap2(G, t - 2);
+            const bool own_row = t < 2 || t == 10;
+            const float g2 = own_row ? (t == 0 ? G.gxm2 : (t == 1 ? G.gxp2 : 0.0f)) : row_gap2(G, t - 2);
             if (g2 * 0.998f < cur) {
-                const int dy = t < 2 ? 0 : row_dy(t - 2), dz = t < 2 ? 0 : row_dz(t - 2);
-                const RowBounds rb = load_row_bounds(g, ((size_t)(G.cz + dz) * ny + (G.cy + dy)) * nx + G.cx);
                 uint32_t a, b;
-                if (t < 2) {
-                    a = t == 0 ? rb.s0 : rb.s2;
-                    b = t == 0 ? rb.s1 : rb.s3;
+                if (own_row) {
+                    const RowBounds rb = ws->rb0[owner];
+                    a = t == 0 ? rb.s0 : (t == 1 ? rb.s2 : rb.s1 + 4);
+                    b = t == 0 ? rb.s1 : (t == 1 ? rb.s3 : rb.s2);
                 } else {
+                    const RowBounds rb = load_row_bounds(g, ((size_t)(G.cz + row_dz(t - 2)) * ny + (G.cy + row_dy(t - 2))) * nx + G.cx);
                     a = (g2 + G.gxm2) * 0.998f < cur ? rb.s0 : rb.s1;
                     b = (g2 + G.gxp2) * 0.998f < cur ? rb.s3 : rb.s2;
                 }
