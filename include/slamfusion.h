@@ -159,6 +159,7 @@ typedef struct {
 } sf_icp_result;
 #define SF_ICP_FLAG_FEW_CORR 1   /* < 10 correspondences: reference returns the initial T */
 #define SF_ICP_FLAG_SINGULAR 2   /* p2plane normal equations not positive definite       */
+#define SF_ICP_FLAG_SHARD_STALE 4 /* sharded stepping: the scan moved out of the margin of this rank's owned-query arrays and stopped; resume with sf_icp_step_begin(first = 2) */
 
 /* modes: REF_CPP = ICPPointToPoint::calculateAlignment (icp_point_to_point.cpp:185-254,
  * lazy re-search, d2 < max_correspondence_dist quirk of :70);  O3D_P2P = Open3D
@@ -216,8 +217,14 @@ int sf_icp_set_query_order(sf_icp *icp, int order);
  *   sf_icp_step_begin  -> NN + partial normal equations into the exchange buffer
  *   (caller all-reduces sf_icp_exchange_ptr over RCCL on sf_ctx_stream)
  *   sf_icp_step_end    -> identical solve on every rank
- * iteration k of n_total; first=1 resets the state to the initial transforms. */
+ * first = 1 starts an alignment (state <- initial transforms; sharded: this rank's owned-query
+ * candidates are compacted, cell-ordered and gathered -- one host synchronisation), first = 0 is
+ * the next iteration.  Sharded: a scan whose points move close to the margin (1 m) of those arrays
+ * stops with SF_ICP_FLAG_SHARD_STALE (same decision on every rank); after the loop the caller
+ * fetches the results and, if any scan carries the flag, calls sf_icp_step_begin(first = 2) --
+ * rebuild at the current poses, flag cleared -- and runs the remaining iterations. */
 int sf_icp_set_shard(sf_icp *icp, float x_lo, float x_hi);
+int sf_icp_set_shard_margin(sf_icp *icp, float margin_m); /* default 1 m: how far a scan may move before its owned-query arrays are rebuilt */
 int sf_icp_set_exchange_buffer(sf_icp *icp, void *d_buf, int64_t nbytes); /* optional: caller-owned (torch tensor) */
 void *sf_icp_exchange_ptr(sf_icp *icp, int64_t *nbytes);
 int sf_icp_step_begin(sf_icp *icp, int mode, int first);

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libslamfusion.so")
 SF_ICP_REF_CPP, SF_ICP_O3D_P2P, SF_ICP_P2PLANE = 0, 1, 2
 SF_VOXEL_PCL, SF_VOXEL_O3D = 0, 1
 SF_FLAG_VOXEL_OVERFLOW = 1
-SF_ICP_FLAG_FEW_CORR, SF_ICP_FLAG_SINGULAR = 1, 2
+SF_ICP_FLAG_FEW_CORR, SF_ICP_FLAG_SINGULAR, SF_ICP_FLAG_SHARD_STALE = 1, 2, 4
 MODES = {"ref_cpp": SF_ICP_REF_CPP, "o3d_p2p": SF_ICP_O3D_P2P, "p2plane": SF_ICP_P2PLANE}
 
 
@@ -455,6 +455,9 @@ class Icp:
         n = C.c_int64()
         p = self.lib.sf_icp_exchange_ptr(self.h, C.byref(n))
         return p, n.value
+
+    def set_shard_margin(self, margin_m):
+        _check(self.lib.sf_icp_set_shard_margin(self.h, C.c_float(margin_m)))
 
     def step_begin(self, mode, first):
         _check(self.lib.sf_icp_step_begin(self.h, C.c_int(MODES[mode]), C.c_int(int(first))))

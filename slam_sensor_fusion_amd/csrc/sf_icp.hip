@@ -41,9 +41,7 @@ struct IcpState {
     float step[12];
     int step_pending;
     int iterations, done, research, n_corr, n_research, flags, converged;
-    // sharded path: pose at which this rank's owned-query list was built, and the rebuild request
-    double T_list[12];
-    int rebuild;
+    double T_list[12]; // sharded path: the pose this rank's owned-query arrays were built at
 };
 
 struct IcpParams {
@@ -411,7 +409,6 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
     s.step_pending = 0;
     s.iterations = s.done = s.research = s.n_corr = s.n_research = s.flags = s.converged = 0;
     for (int i = 0; i < 12; ++i) s.T_list[i] = s.T[i];
-    s.rebuild = 1;
     st[b] = s;
 }
 
@@ -424,7 +421,7 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
 template <int MODE, bool WINDOW, bool SHARD>
 __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                                 int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks,
-                                                const uint32_t *__restrict__ own_list, const uint32_t *__restrict__ own_count)
+                                                const uint32_t *__restrict__ own_off)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in launch order, so
@@ -441,19 +438,16 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
     const IcpState *S = st + b;
     if (S->done) return;
     const int slot = bx * BLK + threadIdx.x;
-    // sharded: this rank walks only its list of owned-query candidates (built with a margin and
-    // rebuilt when the pose has moved, k_own_*); the exact slab predicate is still applied per lane
-    const int n_live = SHARD ? (int)own_count[b] : n;
-    if (SHARD && bx * BLK >= n_live) { // whole workgroup beyond the list: its slab row must still read as zeros
-        if (threadIdx.x < NREC) partials[((size_t)b * nblocks + bx) * REC_STRIDE + threadIdx.x] = 0.0;
-        return;
-    }
+    // sharded: X0x/y/z are this rank's compact arrays of owned-query candidates (slab widened by
+    // the margin at the pose the arrays were built at, cell-ordered, scan b at [own_off[b], own_off[b+1]));
+    // the exact slab predicate is still applied per lane
+    const int n_live = SHARD ? (int)(own_off[b + 1] - own_off[b]) : n;
+    if (SHARD && bx * BLK >= n_live) return; // k_reduce_only reads only the rows that exist
     double sx = 0, sy = 0, sz = 0;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     bool valid = false;
     if (slot < n_live) {
-        const int i = SHARD ? (int)own_list[(size_t)b * n + slot] : slot;
-        const size_t o = (size_t)b * n + i;
+        const size_t o = SHARD ? (size_t)own_off[b] + (size_t)slot : (size_t)b * n + (size_t)slot;
         const double x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
         sx = S->T[0] * x0 + S->T[1] * y0 + S->T[2] * z0 + S->T[3];
         sy = S->T[4] * x0 + S->T[5] * y0 + S->T[6] * z0 + S->T[7];
@@ -579,15 +573,16 @@ __global__ void k_gather_queries(const float *__restrict__ X0x, const float *__r
     Xz[o] = X0z[j];
 }
 
-// ------------------------------------------------------------------ sharded path: owned-query lists
+// ------------------------------------------------------------------ sharded path: owned queries
 // A rank owns the queries whose TRANSFORMED x lies in its slab [xlo, xhi).  Evaluating that per
-// lane over the whole batch leaves 1/N of the lanes of every wave busy (no speed-up); instead
-// each rank keeps, per scan, the list of queries within the slab widened by OWN_MARGIN at the
-// pose T_list, walks only that list, and rebuilds it when any point of the scan's bounding box
-// has moved by more than OWN_MARGIN / 2 since (decided on the device, identically on every
-// rank because every rank holds the same T).  Order-preserving compaction: per-workgroup
-// counts (ballot + popcount), one-workgroup scan per scan, scatter with the mbcnt lane rank.
-constexpr float OWN_MARGIN = 0.5f;
+// lane over the whole batch would leave 1/N of the lanes of every wave busy, so at the start of an
+// alignment each rank compacts, per scan, the queries within the slab widened by a margin (1 m)
+// (order-preserving: per-workgroup counts by ballot + popcount, one-workgroup scan per scan,
+// scatter with the mbcnt lane rank), orders them by map cell like the unsharded path and gathers
+// them into compact arrays; k_nn_red walks only those.  The arrays stay valid while no point of
+// the scan has moved by that margin since: that is checked on the device after every solve
+// (identically on every rank, every rank holds the same T); a scan that moves further stops with
+// SF_ICP_FLAG_SHARD_STALE and the host rebuilds and resumes it (sf_icp_step_begin(first = 2)).
 
 struct ScanBox { float lo[3], hi[3]; };
 
@@ -596,23 +591,34 @@ __device__ __forceinline__ unsigned own_lane_rank(unsigned long long ballot)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0u));
 }
 
-__device__ __forceinline__ bool own_candidate(const IcpState *S, float x0, float y0, float z0, float xlo, float xhi)
+__device__ __forceinline__ bool own_candidate(const IcpState *S, float x0, float y0, float z0, float xlo, float xhi, float margin)
 {
     const float qx = (float)(S->T[0] * (double)x0 + S->T[1] * (double)y0 + S->T[2] * (double)z0 + S->T[3]);
-    return qx >= xlo - OWN_MARGIN && qx < xhi + OWN_MARGIN;
+    return qx >= xlo - margin && qx < xhi + margin;
+}
+
+// resume: scans that stopped because their arrays went stale run again
+__global__ void k_own_resume(IcpState *__restrict__ st, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    if (st[b].flags & SF_ICP_FLAG_SHARD_STALE) {
+        st[b].flags &= ~SF_ICP_FLAG_SHARD_STALE;
+        st[b].done = 0;
+    }
 }
 
 __global__ __launch_bounds__(BLK) void k_own_count(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
-                                                   const IcpState *__restrict__ st, float xlo, float xhi, uint32_t *__restrict__ blk_counts, int nblocks)
+                                                   const IcpState *__restrict__ st, float xlo, float xhi, float margin, uint32_t *__restrict__ blk_counts, int nblocks)
 {
     const int b = blockIdx.y;
     const IcpState *S = st + b;
-    if (S->done || !S->rebuild) return;
+    if (S->done) return;
     const int i = blockIdx.x * BLK + threadIdx.x;
     bool keep = false;
     if (i < n) {
         const size_t o = (size_t)b * n + i;
-        keep = own_candidate(S, X0x[o], X0y[o], X0z[o], xlo, xhi);
+        keep = own_candidate(S, X0x[o], X0y[o], X0z[o], xlo, xhi, margin);
     }
     __shared__ uint32_t wcnt[BLK / 64];
     const unsigned long long bal = __ballot(keep);
@@ -625,7 +631,10 @@ __global__ __launch_bounds__(BLK) void k_own_count(const float *__restrict__ X0x
 __global__ __launch_bounds__(1024) void k_own_scan(const IcpState *__restrict__ st, uint32_t *__restrict__ blk_counts, int nblocks, uint32_t *__restrict__ own_count)
 {
     const int b = blockIdx.x;
-    if (st[b].done || !st[b].rebuild) return;
+    if (st[b].done) {
+        if (threadIdx.x == 0) own_count[b] = 0;
+        return;
+    }
     uint32_t *v = blk_counts + (size_t)b * nblocks;
     __shared__ uint32_t s[1024];
     __shared__ uint32_t carry;
@@ -651,18 +660,19 @@ __global__ __launch_bounds__(1024) void k_own_scan(const IcpState *__restrict__ 
     if (threadIdx.x == 0) own_count[b] = carry;
 }
 
+// own_idx[own_off[b] + rank within the scan] = global query index b * n + i
 __global__ __launch_bounds__(BLK) void k_own_scatter(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
-                                                     const IcpState *__restrict__ st, float xlo, float xhi, const uint32_t *__restrict__ blk_off, int nblocks,
-                                                     uint32_t *__restrict__ own_list)
+                                                     const IcpState *__restrict__ st, float xlo, float xhi, float margin, const uint32_t *__restrict__ blk_off, int nblocks,
+                                                     const uint32_t *__restrict__ own_off, uint32_t *__restrict__ own_idx)
 {
     const int b = blockIdx.y;
     const IcpState *S = st + b;
-    if (S->done || !S->rebuild) return;
+    if (S->done) return;
     const int i = blockIdx.x * BLK + threadIdx.x;
     bool keep = false;
     if (i < n) {
         const size_t o = (size_t)b * n + i;
-        keep = own_candidate(S, X0x[o], X0y[o], X0z[o], xlo, xhi);
+        keep = own_candidate(S, X0x[o], X0y[o], X0z[o], xlo, xhi, margin);
     }
     __shared__ uint32_t wcnt[BLK / 64];
     const unsigned long long bal = __ballot(keep);
@@ -670,23 +680,46 @@ __global__ __launch_bounds__(BLK) void k_own_scatter(const float *__restrict__ X
     if ((threadIdx.x & 63) == 0) wcnt[wv] = (uint32_t)__popcll(bal);
     __syncthreads();
     if (!keep) return;
-    uint32_t off = blk_off[(size_t)b * nblocks + blockIdx.x];
+    uint32_t off = own_off[b] + blk_off[(size_t)b * nblocks + blockIdx.x];
     for (int k = 0; k < wv; ++k) off += wcnt[k];
-    own_list[(size_t)b * n + off + own_lane_rank(bal)] = (uint32_t)i;
+    own_idx[off + own_lane_rank(bal)] = (uint32_t)((size_t)b * n + i);
 }
 
-// after the list was used for the first time: remember the pose it was built at
-__device__ __forceinline__ void own_list_built(IcpState *S)
+// sort keys of the owned queries: scan id, then map cell under the current pose (cf. k_query_keys)
+__global__ void k_own_keys(SfGrid g, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
+                           const uint32_t *__restrict__ own_idx, int64_t total, const IcpState *__restrict__ st, int shift, uint32_t nkeys, uint32_t *__restrict__ keys)
 {
-    if (S->rebuild) {
-        for (int i = 0; i < 12; ++i) S->T_list[i] = S->T[i];
-        S->rebuild = 0;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const uint32_t o = own_idx[e];
+    const int b = (int)(o / (uint32_t)n);
+    const IcpState *S = st + b;
+    const double x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
+    const float qx = (float)(S->T[0] * x0 + S->T[1] * y0 + S->T[2] * z0 + S->T[3]);
+    const float qy = (float)(S->T[4] * x0 + S->T[5] * y0 + S->T[6] * z0 + S->T[7]);
+    const float qz = (float)(S->T[8] * x0 + S->T[9] * y0 + S->T[10] * z0 + S->T[11]);
+    uint32_t key = nkeys - 1;
+    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) {
+        const int cx = (int)fminf(fmaxf(floorf((qx - g.org[0]) * g.inv_h), 0.0f), (float)(g.dim[0] - 1));
+        const int cy = (int)fminf(fmaxf(floorf((qy - g.org[1]) * g.inv_h), 0.0f), (float)(g.dim[1] - 1));
+        const int cz = (int)fminf(fmaxf(floorf((qz - g.org[2]) * g.inv_h), 0.0f), (float)(g.dim[2] - 1));
+        const uint64_t cell = ((uint64_t)cz * (uint64_t)g.dim[1] + (uint64_t)cy) * (uint64_t)g.dim[0] + (uint64_t)cx;
+        key = (uint32_t)(cell >> shift);
     }
+    keys[e] = (uint32_t)b * nkeys + key;
 }
 
-// after a pose update: has any point of the scan's bounding box moved more than OWN_MARGIN / 2
-// since the list was built?  (an affine map of a box moves its corners the most)
-__device__ __forceinline__ void own_check_motion(IcpState *S, const ScanBox &box)
+// the pose the owned arrays were built at
+__global__ void k_own_mark(IcpState *__restrict__ st, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch || st[b].done) return;
+    for (int i = 0; i < 12; ++i) st[b].T_list[i] = st[b].T[i];
+}
+
+// after a pose update: has any point of the scan's bounding box come close to the margin away from
+// where it was when the owned arrays were built?  (an affine map of a box moves its corners the most)
+__device__ __forceinline__ void own_check_motion(IcpState *S, const ScanBox &box, float margin)
 {
     double worst = 0.0;
     for (int c = 0; c < 8; ++c) {
@@ -699,13 +732,17 @@ __device__ __forceinline__ void own_check_motion(IcpState *S, const ScanBox &box
         }
         worst = d2 > worst ? d2 : worst;
     }
-    if (!(worst < 0.25 * (double)OWN_MARGIN * (double)OWN_MARGIN)) S->rebuild = 1;
+    if (!(worst < 0.81 * (double)margin * (double)margin)) {
+        S->flags |= SF_ICP_FLAG_SHARD_STALE;
+        S->done = 1;
+    }
 }
 
 // ------------------------------------------------------------------ solves (thread 0 of the scan's workgroup)
 // Open3D RegistrationICP loop body after a correspondence search (k-th search, K = max_iteration)
 __device__ __forceinline__ void solve_o3d(IcpState *S, const double *rec, int n_src, int k, int K)
 {
+    k = S->n_research; // == the host's loop index on the unsharded path; the state's own count survives a resume
     const double n = rec[0];
     const double fitness = n_src > 0 ? n / (double)n_src : 0.0;
     const double rmse = n > 0 ? sqrt(rec[16] / n) : 0.0;
@@ -784,7 +821,8 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve(IcpState *__restrict__ st
 
 // multi-GPU split: reduce into the exchange buffer, all-reduce outside, then solve
 template <int MODE>
-__global__ __launch_bounds__(RBLK) void k_reduce_only(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, double *__restrict__ xchg)
+__global__ __launch_bounds__(RBLK) void k_reduce_only(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, double *__restrict__ xchg,
+                                                      const uint32_t *__restrict__ own_off)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x;
@@ -793,13 +831,13 @@ __global__ __launch_bounds__(RBLK) void k_reduce_only(IcpState *__restrict__ st,
         if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = 0.0;
         return;
     }
-    reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, nblocks, rec);
+    const int rows = own_off ? (int)((own_off[b + 1] - own_off[b] + BLK - 1) / BLK) : nblocks; // sharded: workgroups beyond the owned queries wrote nothing
+    reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, rows, rec);
     if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = rec[threadIdx.x];
-    if (threadIdx.x == 0) own_list_built(st + b);
 }
 
 template <int MODE>
-__global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict__ xchg, int n_src, int k, int K, int batch, ScanBox box)
+__global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict__ xchg, int n_src, int K, int batch, ScanBox box, float margin)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -811,9 +849,9 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
     for (int c = 0; c < REC_STRIDE; ++c) rec[c] = c < NREC ? xchg[(size_t)b * REC_STRIDE + c] : 0.0;
 #pragma unroll
     for (int c = 0; c < NREC; ++c) S->rec[c] = rec[c];
-    if (MODE == 1) solve_o3d(S, rec, n_src, k, K);
+    if (MODE == 1) solve_o3d(S, rec, n_src, 0, K);
     else solve_plane(S, rec, n_src, K);
-    if (!S->done) own_check_motion(S, box);
+    if (margin > 0.0f && !S->done) own_check_motion(S, box, margin); // sharded path only
 }
 
 // ------------------------------------------------------------------ REF_CPP mode
@@ -987,9 +1025,12 @@ struct sf_icp {
     // sharding
     bool shard = false;
     float xlo = 0, xhi = 0;
-    sf::DevBuf own_list, own_blk, own_count; // sharded path: per-scan owned-query lists
+    sf::DevBuf own_idx, own_blk, own_count, own_off; // sharded path: owned-query compaction
+    std::vector<uint32_t> h_own;                      // host copy of counts / offsets
+    int64_t own_total = 0;                            // owned-query candidates of this rank (all scans)
+    float own_margin = 1.0f;                          // sf_icp_set_shard_margin
+    int own_nblocks = 1;                              // workgroups per scan on the sharded path (largest scan)
     ScanBox box{};                           // bounding box of the source batch (finite points)
-    int step_k = 0;
     int last_mode = 0;
     // graph
     bool use_graph = false;
@@ -1009,11 +1050,29 @@ namespace {
 
 float *soa(sf::DevBuf &b, int64_t total, int axis) { return b.as<float>() + (size_t)axis * (size_t)total; }
 // the query arrays this alignment walks: the cell-ordered copy or the scans as given
-const float *src(sf_icp *icp, int axis) { return soa(icp->ordered ? icp->Xq : icp->X0, icp->n * icp->batch, axis); }
+const float *src(sf_icp *icp, int axis)
+{
+    if (icp->shard) return soa(icp->Xq, icp->own_total, axis); // compact, cell-ordered owned queries (shard_build)
+    return soa(icp->ordered ? icp->Xq : icp->X0, icp->n * icp->batch, axis);
+}
 
 // AUTO orders when there is enough work for the order to pay for the sort (measured: it does from
 // a few scans in flight; one 200 k-point scan gains less than the sort costs)
 constexpr int64_t ORDER_AUTO_MIN_QUERIES = 1000000;
+
+// sort key = scan id, then the map cell (x fastest) shifted down to 24 key bits in all: a finer
+// order gains nothing, a coarser one loses (measured 12..30 bits)
+void order_key_layout(const SfGrid &g, int batch, int *shift, uint32_t *nkeys, int *bits)
+{
+    const uint64_t ncell = (uint64_t)g.dim[0] * (uint64_t)g.dim[1] * (uint64_t)g.dim[2];
+    int bbits = 0, cbits = 0;
+    while ((1u << bbits) < (unsigned)batch) ++bbits;
+    while (cbits < 63 && (1ull << cbits) < ncell) ++cbits;
+    *shift = std::max(0, cbits + bbits - 24);
+    *nkeys = (uint32_t)((ncell - 1) >> *shift) + 1;
+    *bits = 0;
+    while (*bits < 32 && (1ull << *bits) < (uint64_t)*nkeys * (uint64_t)batch) ++*bits;
+}
 
 int order_queries(sf_icp *icp, int mode)
 {
@@ -1022,14 +1081,9 @@ int order_queries(sf_icp *icp, int mode)
     icp->ordered = false;
     if (!want || mode == SF_ICP_REF_CPP || total == 0 || icp->map->grid.n == 0) return SF_OK;
     const SfGrid &g = icp->map->grid;
-    const uint64_t ncell = (uint64_t)g.dim[0] * (uint64_t)g.dim[1] * (uint64_t)g.dim[2];
-    int bbits = 0, cbits = 0;
-    while ((1u << bbits) < (unsigned)icp->batch) ++bbits;
-    while (cbits < 63 && (1ull << cbits) < ncell) ++cbits;
-    const int shift = std::max(0, cbits + bbits - 24); // 24 key bits: finer order gains nothing, coarser loses (measured 12..30)
-    const uint32_t nkeys = (uint32_t)((ncell - 1) >> shift) + 1;
-    int bits = 0;
-    while (bits < 32 && (1ull << bits) < (uint64_t)nkeys * (uint64_t)icp->batch) ++bits;
+    int shift, bits;
+    uint32_t nkeys;
+    order_key_layout(g, icp->batch, &shift, &nkeys, &bits);
     const size_t nb = sizeof(uint32_t) * (size_t)total;
     SF_TRY(icp->Xq.reserve(sizeof(float) * 3 * (size_t)total));
     SF_TRY(icp->qkeys.reserve(nb));
@@ -1126,7 +1180,8 @@ template <int MODE>
 void launch_nn_red(sf_icp *icp, bool sharded = false)
 {
     sf_map *m = icp->map;
-    const dim3 grid((unsigned)((icp->nblocks + 7) & ~7), (unsigned)icp->batch), blk(BLK); // see the XCD mapping in k_nn_red
+    const int nb = sharded ? icp->own_nblocks : icp->nblocks;
+    const dim3 grid((unsigned)((nb + 7) & ~7), (unsigned)icp->batch), blk(BLK); // see the XCD mapping in k_nn_red
     const float *x = src(icp, 0), *y = src(icp, 1), *z = src(icp, 2);
     const IcpState *st = icp->state.as<IcpState>();
     double *part = icp->partials.as<double>();
@@ -1135,8 +1190,8 @@ void launch_nn_red(sf_icp *icp, bool sharded = false)
     ProfScope ps(icp);
     const bool win = m->window.kind != 0;
 #define SF_LAUNCH_NNRED(W, S)                                                                                                                                    \
-    hipLaunchKernelGGL((k_nn_red<MODE, W, S>), grid, blk, 0, s, m->grid, m->window, x, y, z, (int)icp->n, st, thr, icp->xlo, icp->xhi, part, icp->nblocks, \
-                       icp->own_list.as<uint32_t>(), icp->own_count.as<uint32_t>())
+    hipLaunchKernelGGL((k_nn_red<MODE, W, S>), grid, blk, 0, s, m->grid, m->window, x, y, z, (int)icp->n, st, thr, icp->xlo, icp->xhi, part, nb, \
+                       icp->own_off.as<uint32_t>())
     if (win && sharded) SF_LAUNCH_NNRED(true, true);
     else if (win) SF_LAUNCH_NNRED(true, false);
     else if (sharded) SF_LAUNCH_NNRED(false, true);
@@ -1265,7 +1320,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     if (icp->graph_exec) { e = hipGraphExecDestroy(icp->graph_exec); (void)e; }
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
     icp->X0.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
-    icp->partials.release(); icp->xchg_own.release(); icp->own_list.release(); icp->own_blk.release(); icp->own_count.release();
+    icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
     sf_ctx *ctx = icp->ctx;
@@ -1455,6 +1510,13 @@ extern "C" int sf_icp_set_shard(sf_icp *icp, float x_lo, float x_hi)
     return SF_OK;
 }
 
+extern "C" int sf_icp_set_shard_margin(sf_icp *icp, float margin_m)
+{
+    SF_CHECK(icp && margin_m > 0.0f && std::isfinite(margin_m), SF_ERR_INVALID, "the margin must be positive");
+    icp->own_margin = margin_m;
+    return SF_OK;
+}
+
 extern "C" int sf_icp_set_exchange_buffer(sf_icp *icp, void *d_buf, int64_t nbytes)
 {
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
@@ -1472,34 +1534,100 @@ extern "C" void *sf_icp_exchange_ptr(sf_icp *icp, int64_t *nbytes)
     return icp->xchg_own.p;
 }
 
+namespace {
+
+// sharded path, start (or resume) of an alignment: compact this rank's owned-query candidates of
+// every running scan, order them by map cell, gather them into the arrays k_nn_red<SHARD> walks.
+// One host synchronisation (the counts size the sort and the launch grid).
+int shard_build(sf_icp *icp, bool resume)
+{
+    const int B = icp->batch;
+    const int n = (int)icp->n;
+    const int64_t total = icp->n * B;
+    const int nbf = icp->nblocks; // workgroups covering a whole scan
+    hipStream_t s = icp->ctx->stream;
+    IcpState *st = icp->state.as<IcpState>();
+    SF_TRY(icp->own_blk.reserve(sizeof(uint32_t) * (size_t)nbf * (size_t)B));
+    SF_TRY(icp->own_count.reserve(sizeof(uint32_t) * (size_t)B));
+    SF_TRY(icp->own_off.reserve(sizeof(uint32_t) * (size_t)(B + 1)));
+    const float *X = soa(icp->X0, total, 0), *Y = soa(icp->X0, total, 1), *Z = soa(icp->X0, total, 2);
+    const dim3 grid((unsigned)nbf, (unsigned)B);
+    if (resume) hipLaunchKernelGGL(k_own_resume, dim3(nblk(B, 64)), dim3(64), 0, s, st, B);
+    hipLaunchKernelGGL(k_own_count, grid, dim3(BLK), 0, s, X, Y, Z, n, st, icp->xlo, icp->xhi, icp->own_margin, icp->own_blk.as<uint32_t>(), nbf);
+    hipLaunchKernelGGL(k_own_scan, dim3((unsigned)B), dim3(1024), 0, s, st, icp->own_blk.as<uint32_t>(), nbf, icp->own_count.as<uint32_t>());
+    icp->h_own.assign((size_t)B + 1, 0u);
+    SF_HIP(hipMemcpyAsync(icp->h_own.data() + 1, icp->own_count.p, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+    SF_HIP(hipStreamSynchronize(s));
+    uint32_t maxc = 0;
+    for (int b = 0; b < B; ++b) {
+        maxc = std::max(maxc, icp->h_own[(size_t)b + 1]);
+        icp->h_own[(size_t)b + 1] += icp->h_own[(size_t)b]; // counts -> offsets
+    }
+    const int64_t own = (int64_t)icp->h_own[(size_t)B];
+    icp->own_total = own;
+    icp->own_nblocks = (int)std::max<int64_t>(1, sf::div_up((int64_t)maxc, BLK));
+    SF_HIP(hipMemcpyAsync(icp->own_off.p, icp->h_own.data(), sizeof(uint32_t) * (size_t)(B + 1), hipMemcpyHostToDevice, s));
+    const size_t cap = (size_t)std::max<int64_t>(own, 1);
+    SF_TRY(icp->own_idx.reserve(sizeof(uint32_t) * cap));
+    SF_TRY(icp->qkeys.reserve(sizeof(uint32_t) * cap));
+    SF_TRY(icp->qkeys2.reserve(sizeof(uint32_t) * cap));
+    SF_TRY(icp->qidx2.reserve(sizeof(uint32_t) * cap));
+    SF_TRY(icp->Xq.reserve(sizeof(float) * 3 * cap));
+    if (own > 0) {
+        hipLaunchKernelGGL(k_own_scatter, grid, dim3(BLK), 0, s, X, Y, Z, n, st, icp->xlo, icp->xhi, icp->own_margin, icp->own_blk.as<uint32_t>(), nbf, icp->own_off.as<uint32_t>(),
+                           icp->own_idx.as<uint32_t>());
+        const SfGrid &g = icp->map->grid;
+        const uint32_t *order = icp->own_idx.as<uint32_t>(); // as compacted (original order) when the map is empty
+        if (g.n > 0) {
+            int shift, bits;
+            uint32_t nkeys;
+            order_key_layout(g, B, &shift, &nkeys, &bits);
+            hipLaunchKernelGGL(k_own_keys, dim3(nblk(own)), dim3(256), 0, s, g, X, Y, Z, n, icp->own_idx.as<uint32_t>(), own, st, shift, nkeys, icp->qkeys.as<uint32_t>());
+            size_t tmp = 0;
+            hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, icp->qkeys.as<uint32_t>(), icp->qkeys2.as<uint32_t>(), icp->own_idx.as<uint32_t>(),
+                                                     icp->qidx2.as<uint32_t>(), (size_t)own, 0, bits, s);
+            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs(size): %s", hipGetErrorString(e));
+            SF_TRY(sf::ensure_scratch(icp->ctx, tmp));
+            e = rocprim::radix_sort_pairs(icp->ctx->scratch.p, tmp, icp->qkeys.as<uint32_t>(), icp->qkeys2.as<uint32_t>(), icp->own_idx.as<uint32_t>(),
+                                          icp->qidx2.as<uint32_t>(), (size_t)own, 0, bits, s);
+            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs: %s", hipGetErrorString(e));
+            order = icp->qidx2.as<uint32_t>();
+        }
+        hipLaunchKernelGGL(k_gather_queries, dim3(nblk(own)), dim3(256), 0, s, X, Y, Z, order, own, soa(icp->Xq, own, 0), soa(icp->Xq, own, 1), soa(icp->Xq, own, 2));
+    }
+    hipLaunchKernelGGL(k_own_mark, dim3(nblk(B, 64)), dim3(64), 0, s, st, B);
+    SF_HIP(hipGetLastError());
+    return SF_OK;
+}
+
+} // namespace
+
+// first: 1 = start an alignment, 0 = next iteration, 2 = resume the scans that stopped with
+// SF_ICP_FLAG_SHARD_STALE (sharded path: their owned-query arrays are rebuilt at the current pose)
 extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
 {
     SF_TRY(check_ready(icp, mode));
     SF_CHECK(mode != SF_ICP_REF_CPP, SF_ERR_INVALID, "stepping supports O3D_P2P and P2PLANE");
+    SF_CHECK(first >= 0 && first <= 2, SF_ERR_INVALID, "first must be 0, 1 or 2");
+    SF_CHECK(first != 2 || icp->shard, SF_ERR_STATE, "resume (first = 2) is a sharded-path operation");
     SF_HIP(hipSetDevice(icp->ctx->device));
     icp->last_mode = mode;
-    if (first) { launch_state_init(icp); SF_TRY(order_queries(icp, mode)); icp->step_k = 0; }
+    if (first == 1) launch_state_init(icp);
+    if (icp->shard) {
+        if (first) SF_TRY(shard_build(icp, first == 2));
+    } else if (first) {
+        SF_TRY(order_queries(icp, mode));
+    }
     double *x = reinterpret_cast<double *>(sf_icp_exchange_ptr(icp, nullptr));
     hipStream_t s = icp->ctx->stream;
-    if (icp->shard) { // (re)build this rank's owned-query lists where the device asked for it
-        const int64_t total = icp->n * icp->batch;
-        SF_TRY(icp->own_list.reserve(sizeof(uint32_t) * (size_t)std::max<int64_t>(total, 1)));
-        SF_TRY(icp->own_blk.reserve(sizeof(uint32_t) * (size_t)icp->nblocks * (size_t)icp->batch));
-        SF_TRY(icp->own_count.reserve(sizeof(uint32_t) * (size_t)icp->batch));
-        const dim3 grid((unsigned)icp->nblocks, (unsigned)icp->batch);
-        const float *X = src(icp, 0), *Y = src(icp, 1), *Z = src(icp, 2);
-        IcpState *st = icp->state.as<IcpState>();
-        hipLaunchKernelGGL(k_own_count, grid, dim3(BLK), 0, s, X, Y, Z, (int)icp->n, st, icp->xlo, icp->xhi, icp->own_blk.as<uint32_t>(), icp->nblocks);
-        hipLaunchKernelGGL(k_own_scan, dim3((unsigned)icp->batch), dim3(1024), 0, s, st, icp->own_blk.as<uint32_t>(), icp->nblocks, icp->own_count.as<uint32_t>());
-        hipLaunchKernelGGL(k_own_scatter, grid, dim3(BLK), 0, s, X, Y, Z, (int)icp->n, st, icp->xlo, icp->xhi, icp->own_blk.as<uint32_t>(), icp->nblocks,
-                           icp->own_list.as<uint32_t>());
-    }
+    const int nb = icp->shard ? icp->own_nblocks : icp->nblocks;
+    const uint32_t *off = icp->shard ? icp->own_off.as<uint32_t>() : nullptr;
     if (mode == SF_ICP_O3D_P2P) {
         launch_nn_red<1>(icp, icp->shard);
-        hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), icp->nblocks, x);
+        hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off);
     } else {
         launch_nn_red<2>(icp, icp->shard);
-        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), icp->nblocks, x);
+        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off);
     }
     SF_HIP(hipGetLastError());
     return SF_OK;
@@ -1513,10 +1641,9 @@ extern "C" int sf_icp_step_end(sf_icp *icp, int mode, int last)
     hipStream_t s = icp->ctx->stream;
     const int K = icp->prm.num_iters;
     if (mode == SF_ICP_O3D_P2P)
-        hipLaunchKernelGGL(k_solve_only<1>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, icp->step_k, K, icp->batch, icp->box);
+        hipLaunchKernelGGL(k_solve_only<1>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->box, icp->shard ? icp->own_margin : 0.0f);
     else
-        hipLaunchKernelGGL(k_solve_only<2>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, icp->step_k, K, icp->batch, icp->box);
-    icp->step_k += 1;
+        hipLaunchKernelGGL(k_solve_only<2>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->box, icp->shard ? icp->own_margin : 0.0f);
     SF_HIP(hipGetLastError());
     return SF_OK;
 }

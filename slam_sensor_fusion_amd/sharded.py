@@ -25,23 +25,43 @@ def slab_select(map_xyz, edges, rank, halo):
     return np.nonzero((x >= lo) & (x < hi))[0]
 
 
+SF_ICP_FLAG_SHARD_STALE = 4
+
+
 class ShardedIcp:
     """Drives sf_icp_step_begin / all-reduce / sf_icp_step_end for one rank.
 
-    `allreduce(ptr_or_tensor)` is injected: RCCL through torch.distributed on the GPU,
-    gloo in the CPU tests (where `icp` is a numpy stand-in with the same step API).
+    `allreduce()` is injected: RCCL through torch.distributed on the GPU, gloo in the CPU
+    tests (where `icp` is a numpy stand-in with the same step API).  At the start of an
+    alignment every rank compacts and cell-orders the queries it may own (slab + margin); a scan
+    that moves close to that margin stops with SF_ICP_FLAG_SHARD_STALE — the same decision on
+    every rank, they all hold the same pose — and `align()` rebuilds and resumes it.
     """
 
     def __init__(self, icp, mode, num_iterations, allreduce):
         self.icp, self.mode, self.iters, self.allreduce = icp, mode, num_iterations, allreduce
+        self.resumes = 0
 
     def n_steps(self):
         # O3D_P2P evaluates once more after the last update (registration_icp's final search)
         return self.iters + 1 if self.mode == "o3d_p2p" else self.iters
 
-    def align_async(self):
+    def run_pass(self, first):
+        """One pass over all iterations, enqueue only (first: 1 = start, 2 = resume stale scans)."""
         steps = self.n_steps()
         for k in range(steps):
-            self.icp.step_begin(self.mode, first=(k == 0))
+            self.icp.step_begin(self.mode, first=(first if k == 0 else 0))
             self.allreduce()
             self.icp.step_end(self.mode, last=(k == steps - 1))
+
+    def align(self):
+        """Blocking alignment of the batch; returns the per-scan results."""
+        first = 1
+        for _ in range(self.n_steps() + 1):          # every resume completes at least one iteration
+            self.run_pass(first)
+            results = self.icp.fetch_results()
+            if not any(r["flags"] & SF_ICP_FLAG_SHARD_STALE for r in results):
+                return results
+            self.resumes += 1
+            first = 2
+        raise RuntimeError("sharded alignment did not finish")

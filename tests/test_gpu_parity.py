@@ -310,57 +310,76 @@ def test_icp_batch_graph_and_determinism(api, ctx, orc, synth, small_world):
             assert np.array_equal(a[k]["T64"], b[k]["T64"]) and a[k]["iterations"] == b[k]["iterations"]
 
 
-@pytest.mark.parametrize("offset", [0.0, 0.45])
-def test_sharded_steps_equal_single_shot(api, ctx, orc, synth, small_world, offset):
+@pytest.mark.parametrize("offset,margin,resumes", [(0.0, 1.0, 0), (0.45, 1.0, 0), (0.45, 0.2, 1)])
+def test_sharded_steps_equal_single_shot(api, ctx, orc, synth, small_world, offset, margin, resumes):
     """Two x-slabs on one GPU: summing the two exchange records by hand must reproduce the
-    unsharded registration (the multi-GPU path minus RCCL).  offset = 0.45 m starts far enough
-    for the pose to move by more than the owned-list margin / 2, so the lists are rebuilt on the
-    device in mid-alignment."""
+    unsharded registration (the multi-GPU path minus RCCL).  Three scans in flight.  With a 0.2 m
+    margin and a 0.45 m start offset the scans move out of the margin of their owned-query arrays:
+    they stop with SF_ICP_FLAG_SHARD_STALE (on both slabs alike) and the driver resumes them."""
     import torch
     from slam_sensor_fusion_amd import sharded
-    m, scan = small_world["map"], small_world["scan"]
-    init = synth.make_T((offset, 0.0, 0.0), (0, 0, 0))
+    m = small_world["map"]
+    scans = np.stack([synth.make_scan(m, 5000, scan_id=s)[0] for s in range(3)])
+    inits = np.stack([synth.make_T((offset, 0.0, 0.0), (0, 0, 0)), synth.make_T((0.0, 0.0, 0.0), (0, 0, 0)), synth.make_T((0.0, offset / 2, 0.0), (0, 0, 0))])
     edges = sharded.slab_edges(m[:, 0], 2)
     full = api.Map(ctx, api.Cloud(ctx, m), 0.25)
     full.estimate_normals(0.25)
     icp0 = api.Icp(ctx, 0.5, 20, 0.05, 1e-5)
     icp0.set_target(full)
-    icp0.set_source(scan)
-    icp0.set_initial_transformation(init)
-    ref = icp0.align("p2plane")
+    icp0.set_source_batch(scans)
+    icp0.set_initial_batch(inits)
+    ref = icp0.align_batch("p2plane")
     maps, icps = [], []
+    xb = [torch.zeros(3 * 32, dtype=torch.float64, device="cuda") for _ in range(2)]
     for r in range(2):
         keep = sharded.slab_select(m, edges, r, halo=0.5 + 0.25 + 0.25)
         mp = api.Map(ctx, api.Cloud(ctx, m[keep]), 0.25)
         mp.estimate_normals(0.25)
         icp = api.Icp(ctx, 0.5, 20, 0.05, 1e-5)
         icp.set_target(mp)
-        icp.set_source(scan)
-        icp.set_initial_transformation(init)
+        icp.set_source_batch(scans)
+        icp.set_initial_batch(inits)
         icp.set_shard(float(edges[r]), float(edges[r + 1]))
+        icp.set_shard_margin(margin)
+        icp.set_exchange_buffer(xb[r].data_ptr(), 3 * 256)
         maps.append(mp)
         icps.append(icp)
-    xb = [torch.zeros(32, dtype=torch.float64, device="cuda") for _ in range(2)]
-    for icp, x in zip(icps, xb):
-        icp.set_exchange_buffer(x.data_ptr(), 256)
+
+    class BothSlabs:
+        """The two ranks in lock step; the 'all-reduce' is the sum of the two exchange buffers."""
+
+        def step_begin(self, mode, first):
+            for icp in icps:
+                icp.step_begin(mode, first)
+
+        def step_end(self, mode, last):
+            for icp in icps:
+                icp.step_end(mode, last)
+
+        def fetch_results(self):
+            a, b = icps[0].fetch_results(), icps[1].fetch_results()
+            for x, y in zip(a, b):
+                assert np.array_equal(x["T64"], y["T64"]) and x["flags"] == y["flags"] and x["iterations"] == y["iterations"]
+            return a
+
     owned = []
-    for k in range(20):
-        for icp in icps:
-            icp.step_begin("p2plane", first=(k == 0))
+
+    def allreduce():
         ctx.synchronize()
-        owned.append(float(xb[0][0] + xb[1][0]))
-        total = xb[0] + xb[1]                      # what the RCCL all-reduce does across ranks
+        total = xb[0] + xb[1]
+        owned.append(total[0::32].cpu().numpy().copy())
         xb[0].copy_(total)
         xb[1].copy_(total)
         torch.cuda.synchronize()
-        for icp in icps:
-            icp.step_end("p2plane", last=(k == 19))
-    ctx.synchronize()
-    for icp in icps:
-        r = icp.fetch_results()[0]
-        assert r["iterations"] == 20 and r["n_corr"] == ref["n_corr"]
-        assert_pose_close(synth, r["T64"], ref["T64"], 1e-9, 1e-10)
-    assert owned[-1] == ref["n_corr"]             # every query owned by exactly one slab
+
+    drv = sharded.ShardedIcp(BothSlabs(), "p2plane", 20, allreduce)
+    res = drv.align()
+    assert drv.resumes >= resumes and (resumes > 0 or drv.resumes == 0)
+    for k in range(3):
+        assert res[k]["iterations"] == 20 and res[k]["n_corr"] == ref[k]["n_corr"] and res[k]["flags"] == 0
+        assert_pose_close(synth, res[k]["T64"], ref[k]["T64"], 1e-9, 1e-10)
+    final = [o for o in owned if o.any()][-1]
+    assert all(final[k] == ref[k]["n_corr"] or final[k] == 0 for k in range(3))   # every query owned by exactly one slab
 
 
 # ------------------------------------------------------------------ committed golden vectors

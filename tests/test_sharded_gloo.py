@@ -37,8 +37,11 @@ class NumpyShardStep:
         self.T = np.eye(4)
         self.iterations = 0
 
+    def fetch_results(self):
+        return [dict(flags=0, iterations=self.iterations)]
+
     def step_begin(self, mode, first):
-        if first:
+        if first == 1:
             self.T = np.eye(4)
             self.iterations = 0
         s = self.scan @ self.T[:3, :3].T + self.T[:3, 3]
@@ -93,7 +96,8 @@ def worker(rank, world, port, out_dir):
     step = NumpyShardStep(orc, local, normals, scan, edges[rank], edges[rank + 1], xchg)
     drv = sharded.ShardedIcp(step, "p2plane", ITERS, lambda: dist.all_reduce(xchg))
     assert drv.n_steps() == ITERS
-    drv.align_async()
+    res = drv.align()
+    assert res[0]["iterations"] == ITERS and drv.resumes == 0
     np.save(os.path.join(out_dir, "T_%d.npy" % rank), step.T)
     np.save(os.path.join(out_dir, "n_%d.npy" % rank), np.array([step.n_corr, len(local), step.iterations]))
     dist.destroy_process_group()

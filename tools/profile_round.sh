@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence of a round on the GPU box and write the summaries under profiles/:
+#   tools/profile_round.sh r01        (run through gpurun; raw output stays in /tmp on the box)
+# Timing pass: --kernel-trace --stats.  Counter passes: --pmc only, one group per run (gpurun refuses
+# --pmc together with tracing flags).  Command profiled: the default bench workload, 3 steps.
+set -e
+P=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT="$GRAFT_REPO_ROOT/gpurun_out/profiles_$P"
+W=/tmp/prof_$P
+mkdir -p "$OUT" "$W"
+CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph"
+run() { # name, rocprofv3 args...
+    local name=$1; shift
+    rocprofv3 "$@" -d "$W/$name" -o t --output-format csv -- $CMD > "$OUT/$name.log" 2>&1
+    python3 tools/summarize_prof.py "$W/$name" "$OUT/${P}_$name"
+    echo "$name done"
+}
+run final --kernel-trace --stats
+run fetch --pmc FETCH_SIZE
+run write --pmc WRITE_SIZE
+run rdsz --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+run wrsz --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum
+run mem --pmc TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
+run sq --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY
+run sq2 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
+python3 bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${P}_bench_nocpu.json"
+rm -f "$OUT"/*.log
+ls "$OUT"
