@@ -72,12 +72,33 @@ __device__ __forceinline__ void consider(const SfWindow &w, float px, float py, 
     }
 }
 
-// candidates [j, min(j + 4, b)) of a non-empty CSR range: four independent 16-byte loads.  All four
-// are issued unconditionally (indices clamped into the range) so they are in flight together: a
-// predicated load per candidate costs a round trip each (measured)
+// candidates [j, min(j + 4, b)) of a non-empty CSR range: four independent 16-byte loads, issued
+// together.  Measured (TA / TCP counters): the kernel is bound by the number of per-lane accesses
+// the L1 (TCP) has to look up, ~1 per clock per CU -- so a lane must not touch memory for a
+// candidate that does not exist.  A branch per candidate serialises the loads (a round trip
+// each, measured), clamping the index into the range keeps them in flight together but every
+// duplicate is still an access; buffer addressing does both: an out-of-range offset makes the TA
+// drop the lane's access and return zeros, without control flow.
+#ifndef SF_NN_CLAMPED_LOADS
+__device__ __forceinline__ float4 load_point(const SfGrid &g, uint32_t j, bool valid)
+{
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g.pts, 0, (int)((uint32_t)g.n * 16u), 0x00020000);
+    const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, valid ? (int)(j * 16u) : -1, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+#endif
+
 template <bool WINDOW>
 __device__ __forceinline__ void scan4(const SfGrid &g, const SfWindow &w, uint32_t j, uint32_t b, float qx, float qy, float qz, NNHit &hit)
 {
+#ifndef SF_NN_CLAMPED_LOADS
+    const float4 p0 = load_point(g, j, true), p1 = load_point(g, j + 1, j + 1 < b), p2 = load_point(g, j + 2, j + 2 < b), p3 = load_point(g, j + 3, j + 3 < b);
+    consider<WINDOW>(w, p0.x, p0.y, p0.z, (int)j, true, qx, qy, qz, hit);
+    consider<WINDOW>(w, p1.x, p1.y, p1.z, (int)(j + 1), j + 1 < b, qx, qy, qz, hit);
+    consider<WINDOW>(w, p2.x, p2.y, p2.z, (int)(j + 2), j + 2 < b, qx, qy, qz, hit);
+    consider<WINDOW>(w, p3.x, p3.y, p3.z, (int)(j + 3), j + 3 < b, qx, qy, qz, hit);
+#else
     const uint32_t last = b - 1;
     const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
     const float4 p0 = g.pts[j], p1 = g.pts[j1], p2 = g.pts[j2], p3 = g.pts[j3];
@@ -85,6 +106,7 @@ __device__ __forceinline__ void scan4(const SfGrid &g, const SfWindow &w, uint32
     consider<WINDOW>(w, p1.x, p1.y, p1.z, (int)j1, j + 1 < b, qx, qy, qz, hit);
     consider<WINDOW>(w, p2.x, p2.y, p2.z, (int)j2, j + 2 < b, qx, qy, qz, hit);
     consider<WINDOW>(w, p3.x, p3.y, p3.z, (int)j3, j + 3 < b, qx, qy, qz, hit);
+#endif
 }
 
 // CSR candidates [a, b)
@@ -263,6 +285,7 @@ struct WaveNN {
     float4 q[64];
     RowBounds rb0[64];           // bounds of the own cell and its x neighbours (tasks 0, 1, 10)
     uint16_t task[64 * 11];      // owner lane << 4 | t, grouped by t
+    uint32_t spare[160];         // k_nn_red reuses this scratch (32 x 18 doubles) once the search is over
 };
 
 __device__ __forceinline__ unsigned long long pack_hit(float d2, int j) { return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)j; }
