@@ -489,61 +489,6 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
         const double r = ex * nx + ey * ny + ez * nz;
         const double ux = ok ? sx : 0.0, uy = ok ? sy : 0.0, uz = ok ? sz : 0.0; // a non-finite dead query must not turn 0 * s into NaN
         const double J[6] = {uy * nz - uz * ny, uz * nx - ux * nz, ux * ny - uy * nx, nx, ny, nz};
-#ifndef SF_TAIL_BUTTERFLY
-        // The wave's record is the sum over its 64 pairs of u u^T with u = (J0..J5, r, w, ex, ey, ez):
-        // a 16x64 . 64x16 product (11 components used), computed as 16 steps of
-        // v_mfma_f64_16x16x4_f64 over four pairs each.  A lane holds u of ITS pair, the MFMA wants
-        // component (lane & 15) of pair 4 * step + (lane >> 4): the transposition goes through LDS
-        // (the search's scratch is free by now), 32 pairs at a time, rows of 18 doubles (144-byte
-        // stride: the 16-byte row writes of 8 neighbouring lanes cover all banks).  Measured: the
-        // DPP / permlane butterfly this replaces cost 155 of the kernel's 1 060 vector
-        // instructions per wave; the MFMA pipe is otherwise idle.
-        typedef double v4d __attribute__((ext_vector_type(4)));
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        constexpr int USTRIDE = 18;
-        static_assert(sizeof(sf::WaveNN) >= 32 * USTRIDE * sizeof(double), "record transposition scratch");
-        double *U = reinterpret_cast<double *>(&nn_ws[wv]);
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if ((lane >> 5) == half) {
-                v2d *row = reinterpret_cast<v2d *>(U + (lane & 31) * USTRIDE);
-                row[0] = v2d{J[0], J[1]};
-                row[1] = v2d{J[2], J[3]};
-                row[2] = v2d{J[4], J[5]};
-                row[3] = v2d{r, wgt};
-                row[4] = v2d{ex, ey};
-                row[5] = v2d{ez, 0.0};
-                row[6] = v2d{0.0, 0.0};
-                row[7] = v2d{0.0, 0.0};
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int st4 = 0; st4 < 8; ++st4) {
-                const double a = U[(4 * st4 + (lane >> 4)) * USTRIDE + (lane & 15)];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
-            }
-        }
-        // D[i][j] sits in lane j + 16 * (i & 3), register i >> 2 (probed on gfx950); the table maps the
-        // upper-triangle entries the record needs to their slots: [0] n = D[7][7], [1] sum r^2 = D[6][6],
-        // [2..22] JtJ = D[a][c], [23..28] Jtr = D[a][6], [29..31] sum ex^2, ey^2, ez^2 (added below)
-        static __constant__ const uint32_t REC_SLOT[64] = {
-            0xffffff02u, 0xffffff03u, 0xffffff04u, 0xffffff05u, 0xffff1406u, 0xffff1507u, 0xffff1b17u, 0xffffffffu, 0xff1dffffu, 0xffffffffu, 0xffffffffu,
-            0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffff08u, 0xffffff09u, 0xffffff0au, 0xffffff0bu, 0xffff160cu,
-            0xffff1c18u, 0xffffffffu, 0xffffffffu, 0xff1effffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu,
-            0xffffffffu, 0xffffff0du, 0xffffff0eu, 0xffffff0fu, 0xffffff10u, 0xffff0119u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xff1fffffu, 0xffffffffu,
-            0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffff11u, 0xffffff12u, 0xffffff13u, 0xffffff1au,
-            0xffff00ffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        const uint32_t slots = REC_SLOT[lane];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t sl = (slots >> (8 * q)) & 0xffu;
-            if (sl != 0xffu) stage[wv][sl] = acc[q];
-        }
-#else
         {   // record[0..15] = n, sum r^2, JtJ (0,0) (0,1) .. (0,5) (1,1) .. (1,5) (2,2) (2,3) (2,4)
             double v[16];
             v[0] = wgt;
@@ -579,21 +524,12 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
             const double t1 = wave_reduce_16(v);
             if ((lane & 3) == 0) stage[wv][16 + (lane >> 2)] = t1;
         }
-#endif
     }
     __syncthreads();
     if (threadIdx.x < NREC) {
         const int c = threadIdx.x;
         double *dst = partials + ((size_t)b * nblocks + bx) * REC_STRIDE;
-#ifndef SF_TAIL_BUTTERFLY
-        if (MODE == 2 && c == NREC_PLANE - 1) { // sum d^2 arrives as its x, y, z parts
-            double v[BLK / 64];
-#pragma unroll
-            for (int k = 0; k < BLK / 64; ++k) v[k] = (stage[k][29] + stage[k][30]) + stage[k][31];
-            dst[c] = ((v[0] + v[1]) + v[2]) + v[3];
-        } else
-#endif
-            dst[c] = ((stage[0][c] + stage[1][c]) + stage[2][c]) + stage[3][c];
+        dst[c] = ((stage[0][c] + stage[1][c]) + stage[2][c]) + stage[3][c];
     }
 }
 

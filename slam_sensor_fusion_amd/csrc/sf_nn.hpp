@@ -285,7 +285,6 @@ struct WaveNN {
     float4 q[64];
     RowBounds rb0[64];           // bounds of the own cell and its x neighbours (tasks 0, 1, 10)
     uint16_t task[64 * 11];      // owner lane << 4 | t, grouped by t
-    uint32_t spare[160];         // k_nn_red reuses this scratch (32 x 18 doubles) once the search is over
 };
 
 __device__ __forceinline__ unsigned long long pack_hit(float d2, int j) { return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)j; }
