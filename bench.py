@@ -46,6 +46,7 @@ def parse():
                     help="run the sharded stepping path + collective even with one rank (rehearses the RCCL plumbing on one GPU)")
     ap.add_argument("--mode", default="p2plane", choices=["p2plane", "o3d_p2p"])
     ap.add_argument("--cell", type=float, default=0.25)
+    ap.add_argument("--query-order", default="auto", choices=["auto", "as_given", "cell"], help="sf_icp_set_query_order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=20)
@@ -106,6 +107,7 @@ def main():
     icp.set_source_batch(scans)
     icp.set_initial_batch(None)
     icp.use_graph(not args.no_graph)
+    icp.set_query_order(args.query_order)
     xbuf = None
     drv = None
     if sharded_run:
@@ -174,6 +176,7 @@ def main():
         lat.set_target(mp)
         lat.set_source(scans[0])
         lat.use_graph(not args.no_graph)
+        lat.set_query_order(args.query_order)
         lat.align(args.mode)
         tl = time.perf_counter()
         for _ in range(10):

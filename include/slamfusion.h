@@ -206,7 +206,7 @@ int sf_icp_use_graph(sf_icp *icp, int on); /* replay the launch sequence as a hi
  * every per-point term are independent of it; only the rounding of the record sums changes
  * (deterministically for a given order).  CELL sorts each scan by the map-grid cell of its points
  * under the initial pose at the start of every alignment (on the device, inside sf_icp_align*), so
- * that scans in flight share map lines in L2; AUTO = CELL when scans x points >= 1e6. */
+ * that scans in flight share map lines in L2; AUTO = CELL when scans x points >= 300 000. */
 #define SF_ORDER_AUTO 0
 #define SF_ORDER_AS_GIVEN 1
 #define SF_ORDER_CELL 2

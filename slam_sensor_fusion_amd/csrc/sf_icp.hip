@@ -1056,9 +1056,9 @@ const float *src(sf_icp *icp, int axis)
     return soa(icp->ordered ? icp->Xq : icp->X0, icp->n * icp->batch, axis);
 }
 
-// AUTO orders when there is enough work for the order to pay for the sort (measured: it does from
-// a few scans in flight; one 200 k-point scan gains less than the sort costs)
-constexpr int64_t ORDER_AUTO_MIN_QUERIES = 1000000;
+// AUTO orders when there is enough work for the order to pay for the sort.  Measured, 200 k-point
+// scans, 20 iterations: 1 scan in flight +1.5 % (break-even), 2: +8 %, 4: +32 %, 32: +65 %
+constexpr int64_t ORDER_AUTO_MIN_QUERIES = 300000;
 
 // sort key = scan id, then the map cell (x fastest) shifted down to 24 key bits in all: a finer
 // order gains nothing, a coarser one loses (measured 12..30 bits)

@@ -12,7 +12,7 @@ mkdir -p "$OUT" "$W"
 CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph"
 run() { # name, rocprofv3 args...
     local name=$1; shift
-    rocprofv3 "$@" -d "$W/$name" -o t --output-format csv -- $CMD > "$OUT/$name.log" 2>&1
+    timeout -k 10 200 rocprofv3 "$@" -d "$W/$name" -o t --output-format csv -- $CMD > "$OUT/$name.log" 2>&1
     python3 tools/summarize_prof.py "$W/$name" "$OUT/${P}_$name"
     echo "$name done"
 }
@@ -24,6 +24,12 @@ run wrsz --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum
 run mem --pmc TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 run sq --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY
 run sq2 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
-python3 bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${P}_bench_nocpu.json"
+# texture-path units (at most two TA / TD counters fit one pass)
+run ta --pmc TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
+run td --pmc TD_TD_BUSY_sum TD_TC_STALL_sum
+run tcp --pmc TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum
+python3 bench.py 2>/dev/null | tail -1 > "$OUT/${P}_bench_default.json"
+for B in 1 2 4 8 16 64; do python3 bench.py --batch $B --steps 10 --no-cpu-baseline 2>/dev/null | tail -1; done > "$OUT/${P}_bench_sweep.jsonl"
+python3 bench.py --force-dist --steps 10 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${P}_bench_forcedist.json"
 rm -f "$OUT"/*.log
 ls "$OUT"
