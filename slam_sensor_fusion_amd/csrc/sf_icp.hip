@@ -6,11 +6,17 @@
 // registration_icp call of localization_python/localization_python/localization_node.py:
 // 233-237; adds the point-to-plane Gauss-Newton extension.
 //
-// Per iteration (O3D_P2P / P2PLANE):
+// Once per alignment (O3D_P2P / P2PLANE, enough work to pay for it): every scan's points are
+// ordered by the map cell they fall in under the initial pose (k_query_keys, rocPRIM radix sort,
+// k_gather_queries), so that the scans in flight walk the map together.
+// Per iteration:
 //   k_nn_red        one lane per source point: s = T*x0 (float64), exact grid 1-NN of
-//                   float32(s), per-pair contribution accumulated in float64 registers,
-//                   wave64 xor-shuffle reduce -> LDS across the 4 waves -> one partial
-//                   record per workgroup in a slab (no float atomics: bitwise reproducible)
+//                   float32(s) (wave-cooperative, sf_nn.hpp), the pair's contribution in
+//                   float64, wave64 transposing-butterfly reduce (permlane swaps + DPP) -> LDS
+//                   across the 4 waves -> one partial record per workgroup in a slab (no float
+//                   atomics: bitwise reproducible).  Workgroups are placed XCD-aware: every XCD
+//                   sweeps its own contiguous part of the (cell-ordered) chunks for all scans in
+//                   flight, so they share map lines in that XCD's L2.
 //   k_reduce_solve  one workgroup per scan: fixed-order sum of the slab, then one lane
 //                   solves (3x3 Jacobi SVD Kabsch / 6x6 LDL^T), composes T and updates the
 //                   convergence flags in device memory — no host round trip per iteration.

@@ -3,20 +3,22 @@
 // Replaces the N serial FLANN kd-tree descents of
 // localization/src/icp_point_to_point.cpp:64-69 (sourceTargetCorrespondences) and the
 // Open3D hybrid search behind localization_python/.../localization_node.py:233-237.
-// One lane per query.
+// One lane per query.  Two forms: nn_search (each lane on its own; map queries, REF_CPP mode,
+// the brute-force scorer) and nn_search_wave (the 64 lanes of a wave share the work; the ICP hot
+// kernel k_nn_red).
 //
-// Measured on MI355X (profiles/): the kernel is bound by vector-instruction issue
-// under heavy lane divergence (every lane walks its own short candidate lists) with dependent
-// gather round trips behind it, not by HBM bandwidth.  Hence: the map is sorted by cell
-// (x fastest) so a row of cells is one contiguous candidate range; ONE 16-byte look-up returns
-// the bounds of the three cells of a row; the query's own cell is scanned first and the x
-// neighbours / the 8 neighbouring rows only while their gap to the query is smaller than the
-// best distance so far; the rows a query still needs are per-LANE data (a bit mask walked with
-// ffs) and the next row's bounds are requested before the current row is scanned; candidates are
-// fetched four at a time with unconditional (clamped) loads so they are in flight together;
-// the winner's coordinates stay in registers (re-reading them after the search costs a round trip).
-// A per-cell 128-byte bucket layout (one line per visited cell, no bounds look-up) was built
-// and measured: fewer memory requests, but more instructions — slower.
+// Layout: the map is sorted by cell (x fastest), so a row of cells is one contiguous candidate
+// range, and ONE 16-byte look-up returns the bounds of the three cells of a row.  The query's own
+// cell is scanned first; its x neighbours and the 8 neighbouring rows only while their gap to the
+// query is smaller than the best distance so far.
+// What was measured on MI355X and shaped this file (profiles/): a branch per
+// candidate load serialises the loads into one round trip each; clamped duplicate loads keep them
+// in flight together but every duplicate is an L1 access, and the L1 / texture path is what the
+// kernel runs out of -- buffer addressing with an out-of-range offset gives predication without
+// either cost; the winner's coordinates stay in registers (re-reading them costs a round trip);
+// a per-cell 128-byte bucket layout and 32-byte point+normal records were both slower; after
+// the own-cell step only ~6 of 64 lanes have neighbour ranges left to scan, which is why
+// nn_search_wave deals that work out across the wave.
 //
 // Exactness: after scanning the block of radius R around the query's cell, every
 // unscanned point is at least m = distance(query, block boundary) away; the search stops
