@@ -394,11 +394,15 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
 }
 
 // ------------------------------------------------------------------ helper kernels
-__global__ void k_soa_from_aos(const float *__restrict__ aos, int64_t n, float *__restrict__ x, float *__restrict__ y, float *__restrict__ z)
+// source points as SoA (coalesced lane loads of the kernels) and as float4 records (ONE 16-byte access
+// per point for the gather of the query ordering, instead of three scattered 4-byte ones)
+__global__ void k_soa_from_aos(const float *__restrict__ aos, int64_t n, float *__restrict__ x, float *__restrict__ y, float *__restrict__ z, float4 *__restrict__ rec)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    x[i] = aos[3 * i]; y[i] = aos[3 * i + 1]; z[i] = aos[3 * i + 2];
+    const float a = aos[3 * i], b = aos[3 * i + 1], c = aos[3 * i + 2];
+    x[i] = a; y[i] = b; z[i] = c;
+    rec[i] = make_float4(a, b, c, 0.0f);
 }
 
 __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict__ inits, int batch)
@@ -568,15 +572,15 @@ __global__ void k_query_keys(SfGrid g, const float *__restrict__ X0x, const floa
     idx[o] = (uint32_t)o;
 }
 
-__global__ void k_gather_queries(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, const uint32_t *__restrict__ idx,
-                                 int64_t total, float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz)
+__global__ void k_gather_queries(const float4 *__restrict__ rec, const uint32_t *__restrict__ idx, int64_t total, float *__restrict__ Xx, float *__restrict__ Xy,
+                                 float *__restrict__ Xz)
 {
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= total) return;
-    const uint32_t j = idx[o];
-    Xx[o] = X0x[j];
-    Xy[o] = X0y[j];
-    Xz[o] = X0z[j];
+    const float4 v = rec[idx[o]];
+    Xx[o] = v.x;
+    Xy[o] = v.y;
+    Xz[o] = v.z;
 }
 
 // ------------------------------------------------------------------ sharded path: owned queries
@@ -1010,6 +1014,7 @@ struct sf_icp {
     int debug = 0;
     // source
     sf::DevBuf X0, X;        // SoA: x[B*n], y[B*n], z[B*n]
+    sf::DevBuf X0r;          // the same points as float4 records (gather source of the query ordering)
     sf::DevBuf Xq, qkeys, qkeys2, qidx, qidx2; // cell-ordered copy of X0 and the sort's buffers
     int order = SF_ORDER_AUTO;
     bool ordered = false;    // this alignment reads Xq
@@ -1107,7 +1112,7 @@ int order_queries(sf_icp *icp, int mode)
     e = rocprim::radix_sort_pairs(icp->ctx->scratch.p, tmp, icp->qkeys.as<uint32_t>(), icp->qkeys2.as<uint32_t>(), icp->qidx.as<uint32_t>(), icp->qidx2.as<uint32_t>(),
                                   (size_t)total, 0, bits, s);
     SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_gather_queries, dim3(nblk(total)), dim3(256), 0, s, soa(icp->X0, total, 0), soa(icp->X0, total, 1), soa(icp->X0, total, 2),
+    hipLaunchKernelGGL(k_gather_queries, dim3(nblk(total)), dim3(256), 0, s, icp->X0r.as<float4>(),
                        icp->qidx2.as<uint32_t>(), total, soa(icp->Xq, total, 0), soa(icp->Xq, total, 1), soa(icp->Xq, total, 2));
     SF_HIP(hipGetLastError());
     icp->ordered = true;
@@ -1118,6 +1123,7 @@ int icp_alloc(sf_icp *icp, int64_t n, int batch)
 {
     const int64_t total = n * batch;
     SF_TRY(icp->X0.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
+    SF_TRY(icp->X0r.reserve(sizeof(float4) * (size_t)std::max<int64_t>(total, 1)));
     SF_TRY(icp->state.reserve(sizeof(IcpState) * (size_t)batch));
     SF_TRY(icp->d_inits.reserve(sizeof(double) * 16 * (size_t)batch));
     icp->nblocks = (int)std::max<int64_t>(1, sf::div_up(n, BLK));
@@ -1140,7 +1146,7 @@ int icp_set_source_device_aos(sf_icp *icp, const float *d_aos, int64_t n, int ba
     const int64_t total = n * batch;
     if (total > 0)
         hipLaunchKernelGGL(k_soa_from_aos, dim3(nblk(total)), dim3(256), 0, icp->ctx->stream, d_aos, total, soa(icp->X0, total, 0), soa(icp->X0, total, 1),
-                           soa(icp->X0, total, 2));
+                           soa(icp->X0, total, 2), icp->X0r.as<float4>());
     SF_HIP(hipGetLastError());
     sf::MinMaxHost mm; // bounding box of the batch: the sharded path's list-rebuild rule needs it
     SF_TRY(sf::cloud_minmax(icp->ctx, d_aos, total, &mm));
@@ -1325,7 +1331,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     (void)e;
     if (icp->graph_exec) { e = hipGraphExecDestroy(icp->graph_exec); (void)e; }
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
-    icp->X0.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
+    icp->X0.release(); icp->X0r.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
     icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
@@ -1599,7 +1605,7 @@ int shard_build(sf_icp *icp, bool resume)
             SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs: %s", hipGetErrorString(e));
             order = icp->qidx2.as<uint32_t>();
         }
-        hipLaunchKernelGGL(k_gather_queries, dim3(nblk(own)), dim3(256), 0, s, X, Y, Z, order, own, soa(icp->Xq, own, 0), soa(icp->Xq, own, 1), soa(icp->Xq, own, 2));
+        hipLaunchKernelGGL(k_gather_queries, dim3(nblk(own)), dim3(256), 0, s, icp->X0r.as<float4>(), order, own, soa(icp->Xq, own, 0), soa(icp->Xq, own, 1), soa(icp->Xq, own, 2));
     }
     hipLaunchKernelGGL(k_own_mark, dim3(nblk(B, 64)), dim3(64), 0, s, st, B);
     SF_HIP(hipGetLastError());

@@ -104,7 +104,8 @@ extern "C" void sf_map_destroy(sf_map *m)
 extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
 {
     SF_CHECK(m && cloud, SF_ERR_INVALID, "bad arguments");
-    SF_CHECK(cloud->n < (int64_t)0x7fffffff, SF_ERR_OVERFLOW, "map too large for 32-bit point ids");
+    // the search addresses candidates through a buffer descriptor (byte offsets and size in 32 bits, sf_nn.hpp)
+    SF_CHECK(cloud->n < (int64_t)(1 << 28), SF_ERR_OVERFLOW, "map too large for one GPU index (2^28 points): shard it");
     sf_ctx *ctx = m->ctx;
     SF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;

@@ -75,8 +75,15 @@ def test_registration_200k_vs_2m(api, ctx, synth, world_2m):
         assert r["iterations"] == 20 and r["fitness"] > 0.999
         assert dt < 2e-4 and dr < 1e-5                                  # 200k points: noise floor ~ sigma / sqrt(N)
     icp.set_source(scans[1])
-    single = icp.align("p2plane")
-    assert np.array_equal(single["T64"], res[1]["T64"])                 # batched == single, bitwise
+    single = icp.align("p2plane")                                       # AUTO: the batch was cell-ordered, one scan is not
+    assert np.abs(single["T64"] - res[1]["T64"]).max() < 1e-12 and single["n_corr"] == res[1]["n_corr"]
+    for order in ("cell", "as_given"):                                  # same order: batched == single, bitwise
+        icp.set_query_order(order)
+        icp.set_source_batch(scans)
+        both = icp.align_batch("p2plane")
+        icp.set_source(scans[1])
+        assert np.array_equal(icp.align("p2plane")["T64"], both[1]["T64"])
+    icp.set_query_order("auto")
     icp.set_num_iterations(30)
     r = icp.align("o3d_p2p")
     dt, dr = synth.pose_error(r["T64"], synth.t_true())
