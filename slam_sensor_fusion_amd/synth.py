@@ -91,3 +91,76 @@ def make_stream(n_scans, seed=STREAM_SEED):
     return dict(truth=np.array(truth), odom=np.array(odom), gps_xyz=np.array(gps_xyz),
                 compass=np.array(compass), gps_cov=np.diag([0.25, 0.25, 0.25]),
                 odom_cov=np.diag([1e-4] * 6))
+
+
+# ------------------------------------------------------------------ config 5: ring-structured scan vs a city map
+CITY_SEED = 4000
+
+
+def make_city(extent_m, n_boxes, seed=CITY_SEED):
+    """Ground plane z = 0 over [-extent/2, extent/2]^2 plus seeded axis-aligned boxes (buildings).
+    Returns boxes[n, 6] = (x0, y0, z0, x1, y1, z1) with z0 = 0."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.uniform(-extent_m / 2, extent_m / 2, (n_boxes, 2))
+    half = rng.uniform(3.0, 12.0, (n_boxes, 2))
+    h = rng.uniform(3.0, 30.0, n_boxes)
+    keep = np.linalg.norm(c, axis=1) > 15.0          # keep the sensor's start area free
+    c, half, h = c[keep], half[keep], h[keep]
+    return np.c_[c - half, np.zeros(len(c)), c + half, h]
+
+
+def sample_city(boxes, extent_m, m_points, sigma=0.005, seed=CITY_SEED + 1):
+    """M points on the city's surfaces (ground, walls, roofs), uniform by area, with sigma noise."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    dx, dy, dz = boxes[:, 3] - boxes[:, 0], boxes[:, 4] - boxes[:, 1], boxes[:, 5]
+    # faces: ground, then per box: roof, 2 walls normal to x, 2 walls normal to y
+    areas = np.concatenate([[extent_m * extent_m], dx * dy, dy * dz, dy * dz, dx * dz, dx * dz])
+    nb = len(boxes)
+    face = rng.choice(len(areas), size=m_points, p=areas / areas.sum())
+    u, v = rng.uniform(0, 1, m_points), rng.uniform(0, 1, m_points)
+    p = np.empty((m_points, 3))
+    g = face == 0
+    p[g] = np.c_[(u[g] - 0.5) * extent_m, (v[g] - 0.5) * extent_m, np.zeros(g.sum())]
+    for kind in range(5):
+        sel = (face >= 1 + kind * nb) & (face < 1 + (kind + 1) * nb)
+        b = boxes[face[sel] - 1 - kind * nb]
+        uu, vv = u[sel], v[sel]
+        x = b[:, 0] + uu * (b[:, 3] - b[:, 0])
+        y = b[:, 1] + (vv if kind == 0 else uu) * (b[:, 4] - b[:, 1])
+        z = vv * b[:, 5]
+        if kind == 0:
+            p[sel] = np.c_[x, y, b[:, 5]]
+        elif kind == 1:
+            p[sel] = np.c_[b[:, 0], y, z]
+        elif kind == 2:
+            p[sel] = np.c_[b[:, 3], y, z]
+        elif kind == 3:
+            p[sel] = np.c_[x, b[:, 1], z]
+        else:
+            p[sel] = np.c_[x, b[:, 4], z]
+    p += rng.normal(0.0, sigma, p.shape)
+    return p.astype(np.float32)
+
+
+def raycast_scan(boxes, T_sensor, rings=64, azimuths=2032, elev_deg=(-24.8, 2.0), max_range=80.0, sigma=NOISE_SIGMA, seed=CITY_SEED + 2):
+    """Spinning-LiDAR scan (rings x azimuths rays, ring-major order like a driver's packet order)
+    of the city from the pose T_sensor (map <- sensor).  Returns the hits in the SENSOR frame."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    el = np.radians(np.linspace(elev_deg[0], elev_deg[1], rings))[:, None]
+    az = np.linspace(0.0, 2 * np.pi, azimuths, endpoint=False)[None, :]
+    d_s = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el) * np.ones_like(az)], -1).reshape(-1, 3)
+    T = np.asarray(T_sensor, dtype=np.float64)
+    o, d = T[:3, 3], d_s @ T[:3, :3].T
+    t_hit = np.full(len(d), np.inf)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tg = -o[2] / d[:, 2]                                        # ground z = 0
+        t_hit = np.where((d[:, 2] < 0) & (tg > 0), tg, t_hit)
+        inv = 1.0 / d
+        for b in boxes:                                             # slab test per box, all rays at once
+            t0, t1 = (b[:3] - o) * inv, (b[3:] - o) * inv
+            tn, tf = np.minimum(t0, t1).max(1), np.maximum(t0, t1).min(1)
+            hit = (tn <= tf) & (tn > 0)
+            t_hit = np.where(hit & (tn < t_hit), tn, t_hit)
+    ok = t_hit < max_range
+    p = d_s[ok] * t_hit[ok, None] + rng.normal(0.0, sigma, (ok.sum(), 3))
+    return p.astype(np.float32)
