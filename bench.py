@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--mode", default="p2plane", choices=["p2plane", "o3d_p2p"])
     ap.add_argument("--cell", type=float, default=0.25)
     ap.add_argument("--query-order", default="auto", choices=["auto", "as_given", "cell"], help="sf_icp_set_query_order")
+    ap.add_argument("--no-nn-reuse", action="store_true", help="sf_icp_set_nn_reuse(0): search every query in every iteration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=20)
@@ -108,6 +109,7 @@ def main():
     icp.set_initial_batch(None)
     icp.use_graph(not args.no_graph)
     icp.set_query_order(args.query_order)
+    icp.set_nn_reuse(not args.no_nn_reuse)
     xbuf = None
     drv = None
     if sharded_run:
@@ -177,6 +179,7 @@ def main():
         lat.set_source(scans[0])
         lat.use_graph(not args.no_graph)
         lat.set_query_order(args.query_order)
+        lat.set_nn_reuse(not args.no_nn_reuse)
         lat.align(args.mode)
         tl = time.perf_counter()
         for _ in range(10):

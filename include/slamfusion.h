@@ -211,6 +211,12 @@ int sf_icp_use_graph(sf_icp *icp, int on); /* replay the launch sequence as a hi
 #define SF_ORDER_AS_GIVEN 1
 #define SF_ORDER_CELL 2
 int sf_icp_set_query_order(sf_icp *icp, int order);
+/* Neighbour reuse (default on, O3D_P2P / P2PLANE).  Every full search also proves a lower bound on
+ * the distance from the query to every map point other than its neighbour; in a later iteration a
+ * query that has moved by less than the slack of that bound provably keeps its neighbour, and its
+ * search is skipped.  Results are bit-identical with the switch on or off (tested); it only
+ * changes how much of the "nearest neighbour every iteration" work has to be redone. */
+int sf_icp_set_nn_reuse(sf_icp *icp, int on);
 
 /* multi-GPU (map tile-sharded along x with halo): this rank only
  * accumulates queries whose TRANSFORMED x lies in [x_lo, x_hi); per iteration

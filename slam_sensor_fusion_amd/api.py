@@ -422,6 +422,9 @@ class Icp:
     def use_graph(self, on=True):
         _check(self.lib.sf_icp_use_graph(self.h, C.c_int(int(on))))
 
+    def set_nn_reuse(self, on=True):
+        _check(self.lib.sf_icp_set_nn_reuse(self.h, C.c_int(int(on))))
+
     def set_query_order(self, order="auto"):
         """'auto' | 'as_given' | 'cell' (SF_ORDER_*): the order a scan's points are walked in."""
         _check(self.lib.sf_icp_set_query_order(self.h, C.c_int({"auto": 0, "as_given": 1, "cell": 2}[order])))

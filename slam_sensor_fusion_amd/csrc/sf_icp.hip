@@ -431,7 +431,7 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
 template <int MODE, bool WINDOW, bool SHARD>
 __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                                 int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks,
-                                                const uint32_t *__restrict__ own_off)
+                                                const uint32_t *__restrict__ own_off, float4 *__restrict__ qcache, int32_t *__restrict__ jcache)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in launch order, so
@@ -456,8 +456,9 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
     double sx = 0, sy = 0, sz = 0;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     bool valid = false;
+    size_t o = 0;
     if (slot < n_live) {
-        const size_t o = SHARD ? (size_t)own_off[b] + (size_t)slot : (size_t)b * n + (size_t)slot;
+        o = SHARD ? (size_t)own_off[b] + (size_t)slot : (size_t)b * n + (size_t)slot;
         const double x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
         sx = S->T[0] * x0 + S->T[1] * y0 + S->T[2] * z0 + S->T[3];
         sy = S->T[4] * x0 + S->T[5] * y0 + S->T[6] * z0 + S->T[7];
@@ -465,9 +466,49 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
         qx = (float)sx; qy = (float)sy; qz = (float)sz;
         valid = !SHARD || (qx >= xlo && qx < xhi);
     }
+    // Neighbour reuse with an exactness certificate.  The last full search of this query (at position
+    // c.xyz) found neighbour jc and proved every OTHER map point at least c.w away.  The query has
+    // moved by delta since; if |q - p_jc| < c.w - delta (triangle inequality, with a rounding margin)
+    // no other point can be nearer, so the search would return jc again -- it is skipped, the
+    // result is bit-identical.  ICP steps shrink geometrically, so after the first few iterations
+    // whole waves certify; a wave with any lane left runs the search for just those lanes.
+    sf::NNHit hit;
+    hit.d2 = thr;
+    hit.j = -1;
+    hit.px = hit.py = hit.pz = 0.0f;
+    hit.lb2 = 0.0f;
+    bool need = valid;
+    if (qcache && valid) {
+        const float4 c = qcache[o];
+        const int32_t jc = jcache[o];
+        if (c.w > 0.0f) {
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (jc >= 0) p = g.pts[jc];
+            const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+            const float reach = c.w * 0.9999f - sqrtf(dx * dx + dy * dy + dz * dz) * 1.0001f - 1.0e-6f;
+            if (jc >= 0) {
+                const float d2n = sf::l2_simple(qx, qy, qz, p.x, p.y, p.z);
+                if (sqrtf(d2n) * 1.0001f + 1.0e-6f < reach) {
+                    need = false;
+                    if (d2n < thr) { hit.d2 = d2n; hit.j = jc; hit.px = p.x; hit.py = p.y; hit.pz = p.z; }
+                }
+            } else if (sqrtf(thr) * 1.0001f + 1.0e-6f < reach) {
+                need = false; // still nothing within the acceptance radius
+            }
+        }
+    }
     // every lane takes part in the search (lanes without a query still execute other lanes' tasks)
     __shared__ sf::WaveNN nn_ws[BLK / 64];
-    const sf::NNHit hit = sf::nn_search_wave<WINDOW>(g, w, valid, qx, qy, qz, thr, &nn_ws[threadIdx.x >> 6]);
+    if (__ballot(need) != 0ull) {
+        const sf::NNHit h = sf::nn_search_wave<WINDOW>(g, w, need, qx, qy, qz, thr, &nn_ws[threadIdx.x >> 6]);
+        if (need) {
+            hit = h;
+            if (qcache) {
+                qcache[o] = make_float4(qx, qy, qz, sqrtf(h.lb2));
+                jcache[o] = h.j;
+            }
+        }
+    }
     // contribution of this lane's pair, reduced over the wave in two halves of 16 values
     // (keeps the live registers low enough for 4+ waves per SIMD), staged per wave in LDS
     __shared__ double stage[BLK / 64][32];
@@ -1026,6 +1067,8 @@ struct sf_icp {
     // source
     sf::DevBuf X0, X;        // SoA: x[B*n], y[B*n], z[B*n]
     sf::DevBuf X0r;          // the same points as float4 records (gather source of the query ordering)
+    sf::DevBuf qcache, jcache; // neighbour reuse: position / runner-up bound (float4) and neighbour (int32) of each query's last full search
+    bool reuse = true;       // sf_icp_set_nn_reuse
     sf::DevBuf Xq, qkeys, qkeys2, qidx, qidx2; // cell-ordered copy of X0 and the sort's buffers
     int order = SF_ORDER_AUTO;
     bool ordered = false;    // this alignment reads Xq
@@ -1095,6 +1138,17 @@ void order_key_layout(const SfGrid &g, int batch, int *shift, uint32_t *nkeys, i
     *nkeys = (uint32_t)((ncell - 1) >> *shift) + 1;
     *bits = 0;
     while (*bits < 32 && (1ull << *bits) < (uint64_t)*nkeys * (uint64_t)batch) ++*bits;
+}
+
+// neighbour reuse starts empty at every alignment (a zero bound certifies nothing)
+int reuse_reset(sf_icp *icp, int64_t count)
+{
+    if (!icp->reuse) return SF_OK;
+    const size_t c = (size_t)std::max<int64_t>(count, 1);
+    SF_TRY(icp->qcache.reserve(sizeof(float4) * c));
+    SF_TRY(icp->jcache.reserve(sizeof(int32_t) * c));
+    SF_HIP(hipMemsetAsync(icp->qcache.p, 0, sizeof(float4) * c, icp->ctx->stream));
+    return SF_OK;
 }
 
 int order_queries(sf_icp *icp, int mode)
@@ -1215,7 +1269,7 @@ void launch_nn_red(sf_icp *icp, bool sharded = false)
     const bool win = m->window.kind != 0;
 #define SF_LAUNCH_NNRED(W, S)                                                                                                                                    \
     hipLaunchKernelGGL((k_nn_red<MODE, W, S>), grid, blk, 0, s, m->grid, m->window, x, y, z, (int)icp->n, st, thr, icp->xlo, icp->xhi, part, nb, \
-                       icp->own_off.as<uint32_t>())
+                       icp->own_off.as<uint32_t>(), icp->reuse ? icp->qcache.as<float4>() : nullptr, icp->jcache.as<int32_t>())
     if (win && sharded) SF_LAUNCH_NNRED(true, true);
     else if (win) SF_LAUNCH_NNRED(true, false);
     else if (sharded) SF_LAUNCH_NNRED(false, true);
@@ -1343,7 +1397,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     (void)e;
     if (icp->graph_exec) { e = hipGraphExecDestroy(icp->graph_exec); (void)e; }
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
-    icp->X0.release(); icp->X0r.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
+    icp->X0.release(); icp->X0r.release(); icp->qcache.release(); icp->jcache.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
     icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
@@ -1447,6 +1501,14 @@ extern "C" int sf_icp_set_query_order(sf_icp *icp, int order)
     return SF_OK;
 }
 
+extern "C" int sf_icp_set_nn_reuse(sf_icp *icp, int on)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    icp->reuse = on != 0;
+    if (icp->graph_exec) { hipError_t e = hipGraphExecDestroy(icp->graph_exec); (void)e; icp->graph_exec = nullptr; } // the captured launches carry the cache pointers
+    return SF_OK;
+}
+
 extern "C" int sf_icp_use_graph(sf_icp *icp, int on)
 {
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
@@ -1462,6 +1524,7 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     icp->last_mode = mode;
     launch_state_init(icp);
     SF_TRY(order_queries(icp, mode)); // plain launches ahead of the (replayed) iteration graph
+    if (mode != SF_ICP_REF_CPP) SF_TRY(reuse_reset(icp, icp->n * icp->batch));
     if (icp->use_graph && !icp->profiling) {
         const bool hit = icp->graph_exec && icp->graph_mode == mode && icp->graph_iters == icp->prm.num_iters && icp->graph_batch == icp->batch &&
                          icp->graph_n == icp->n && icp->graph_map == (const void *)icp->map->grid.pts && icp->graph_window == icp->map->window.kind &&
@@ -1621,7 +1684,7 @@ int shard_build(sf_icp *icp, bool resume)
     }
     hipLaunchKernelGGL(k_own_mark, dim3(nblk(B, 64)), dim3(64), 0, s, st, B);
     SF_HIP(hipGetLastError());
-    return SF_OK;
+    return reuse_reset(icp, own); // the compact indices have changed
 }
 
 } // namespace
@@ -1641,6 +1704,7 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
         if (first) SF_TRY(shard_build(icp, first == 2));
     } else if (first) {
         SF_TRY(order_queries(icp, mode));
+        SF_TRY(reuse_reset(icp, icp->n * icp->batch));
     }
     double *x = reinterpret_cast<double *>(sf_icp_exchange_ptr(icp, nullptr));
     hipStream_t s = icp->ctx->stream;

@@ -34,6 +34,7 @@ struct NNHit {
     float d2;         // squared distance of the best candidate (== threshold if none)
     int j;            // sorted position of the best candidate, -1 if none
     float px, py, pz; // its coordinates (kept in registers: re-reading the winner costs a round trip)
+    float lb2;        // nn_search_wave only: every OTHER map point is at least sqrt(lb2) away from the query
 };
 
 __device__ __forceinline__ float l2_simple(float qx, float qy, float qz, float px, float py, float pz)
@@ -61,16 +62,18 @@ __device__ __forceinline__ bool window_accepts(const SfWindow &w, float px, floa
     return true;
 }
 
-template <bool WINDOW>
+// TRACK: hit.lb2 follows the smallest squared distance among the examined candidates that did
+// not end up as the best (a displaced best included)
+template <bool WINDOW, bool TRACK = false>
 __device__ __forceinline__ void consider(const SfWindow &w, float px, float py, float pz, int j, bool valid, float qx, float qy, float qz, NNHit &hit)
 {
     const float d2 = l2_simple(qx, qy, qz, px, py, pz);
-    if (valid && d2 < hit.d2) {
-        if (!WINDOW || window_accepts(w, px, py, pz)) {
-            hit.d2 = d2;
-            hit.j = j;
-            hit.px = px; hit.py = py; hit.pz = pz;
-        }
+    const bool take = valid && d2 < hit.d2 && (!WINDOW || window_accepts(w, px, py, pz));
+    if (TRACK && valid) hit.lb2 = fminf(hit.lb2, take ? hit.d2 : d2);
+    if (take) {
+        hit.d2 = d2;
+        hit.j = j;
+        hit.px = px; hit.py = py; hit.pz = pz;
     }
 }
 
@@ -91,31 +94,31 @@ __device__ __forceinline__ float4 load_point(const SfGrid &g, uint32_t j, bool v
 }
 #endif
 
-template <bool WINDOW>
+template <bool WINDOW, bool TRACK = false>
 __device__ __forceinline__ void scan4(const SfGrid &g, const SfWindow &w, uint32_t j, uint32_t b, float qx, float qy, float qz, NNHit &hit)
 {
 #ifndef SF_NN_CLAMPED_LOADS
     const float4 p0 = load_point(g, j, true), p1 = load_point(g, j + 1, j + 1 < b), p2 = load_point(g, j + 2, j + 2 < b), p3 = load_point(g, j + 3, j + 3 < b);
-    consider<WINDOW>(w, p0.x, p0.y, p0.z, (int)j, true, qx, qy, qz, hit);
-    consider<WINDOW>(w, p1.x, p1.y, p1.z, (int)(j + 1), j + 1 < b, qx, qy, qz, hit);
-    consider<WINDOW>(w, p2.x, p2.y, p2.z, (int)(j + 2), j + 2 < b, qx, qy, qz, hit);
-    consider<WINDOW>(w, p3.x, p3.y, p3.z, (int)(j + 3), j + 3 < b, qx, qy, qz, hit);
+    consider<WINDOW, TRACK>(w, p0.x, p0.y, p0.z, (int)j, true, qx, qy, qz, hit);
+    consider<WINDOW, TRACK>(w, p1.x, p1.y, p1.z, (int)(j + 1), j + 1 < b, qx, qy, qz, hit);
+    consider<WINDOW, TRACK>(w, p2.x, p2.y, p2.z, (int)(j + 2), j + 2 < b, qx, qy, qz, hit);
+    consider<WINDOW, TRACK>(w, p3.x, p3.y, p3.z, (int)(j + 3), j + 3 < b, qx, qy, qz, hit);
 #else
     const uint32_t last = b - 1;
     const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
     const float4 p0 = g.pts[j], p1 = g.pts[j1], p2 = g.pts[j2], p3 = g.pts[j3];
-    consider<WINDOW>(w, p0.x, p0.y, p0.z, (int)j, true, qx, qy, qz, hit);
-    consider<WINDOW>(w, p1.x, p1.y, p1.z, (int)j1, j + 1 < b, qx, qy, qz, hit);
-    consider<WINDOW>(w, p2.x, p2.y, p2.z, (int)j2, j + 2 < b, qx, qy, qz, hit);
-    consider<WINDOW>(w, p3.x, p3.y, p3.z, (int)j3, j + 3 < b, qx, qy, qz, hit);
+    consider<WINDOW, TRACK>(w, p0.x, p0.y, p0.z, (int)j, true, qx, qy, qz, hit);
+    consider<WINDOW, TRACK>(w, p1.x, p1.y, p1.z, (int)j1, j + 1 < b, qx, qy, qz, hit);
+    consider<WINDOW, TRACK>(w, p2.x, p2.y, p2.z, (int)j2, j + 2 < b, qx, qy, qz, hit);
+    consider<WINDOW, TRACK>(w, p3.x, p3.y, p3.z, (int)j3, j + 3 < b, qx, qy, qz, hit);
 #endif
 }
 
 // CSR candidates [a, b)
-template <bool WINDOW>
+template <bool WINDOW, bool TRACK = false>
 __device__ __forceinline__ void scan_range(const SfGrid &g, const SfWindow &w, uint32_t a, uint32_t b, float qx, float qy, float qz, NNHit &hit)
 {
-    for (uint32_t j = a; j < b; j += 4) scan4<WINDOW>(g, w, j, b, qx, qy, qz, hit);
+    for (uint32_t j = a; j < b; j += 4) scan4<WINDOW, TRACK>(g, w, j, b, qx, qy, qz, hit);
 }
 
 // cell_start[c-1 .. c+2] in ONE 16-byte load (the table carries one pad entry in front, so
@@ -263,6 +266,7 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
     hit.d2 = thr;
     hit.j = -1;
     hit.px = hit.py = hit.pz = 0.0f;
+    hit.lb2 = 0.0f;
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || g.n == 0) return hit;
     nn_rings<WINDOW>(g, w, qx, qy, qz, 1, hit);
     return hit;
@@ -284,6 +288,7 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
 // started from, so the result does not depend on the order in which lanes finish.
 struct WaveNN {
     unsigned long long best[64]; // (float bits of d2) << 32 | j; j = 0xffffffff: none
+    uint32_t lb2[64];            // float bits: lower bound of the squared distance to every point but the best
     float4 q[64];
     RowBounds rb0[64];           // bounds of the own cell and its x neighbours (tasks 0, 1, 10)
     uint16_t task[64 * 11];      // owner lane << 4 | t, grouped by t
@@ -330,7 +335,11 @@ __device__ __forceinline__ float row_gap2(const QueryGeo &G, int k)
     return ry * ry + rz * rz;
 }
 
-// every lane of the wave must call this (lanes without a query pass valid = false: they still work)
+// every lane of the wave must call this (lanes without a query pass valid = false: they still work).
+// Besides the nearest neighbour the result carries lb2: a lower bound of the squared distance from
+// the query to every OTHER map point (the runner-up among the examined candidates, the gaps of
+// everything that was pruned, the boundary of the 27-cell block) -- what k_nn_red needs to prove,
+// one iteration later, that the neighbour cannot have changed.
 template <bool WINDOW>
 __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow &w, bool valid, float qx, float qy, float qz, float thr, WaveNN *ws)
 {
@@ -340,23 +349,39 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
     hit.d2 = thr;
     hit.j = -1;
     hit.px = hit.py = hit.pz = 0.0f;
+    hit.lb2 = 3.0e38f;
     valid = valid && isfinite(qx) && isfinite(qy) && isfinite(qz) && g.n > 0;
     uint32_t mask = 0;
     if (valid) {
         const QueryGeo G = query_geo(g, qx, qy, qz);
         const RowBounds rb0 = load_row_bounds(g, ((size_t)G.cz * ny + G.cy) * nx + G.cx);
         ws->rb0[lane] = rb0;
-        if (rb0.s1 < rb0.s2) scan4<WINDOW>(g, w, rb0.s1, rb0.s2, qx, qy, qz, hit);
-        if (rb0.s1 + 4 < rb0.s2 && hit.d2 > 0.0f) mask |= 1u << 10;
-        if (G.gxm2 * 0.998f < hit.d2 && rb0.s0 < rb0.s1) mask |= 1u;
-        if (G.gxp2 * 0.998f < hit.d2 && rb0.s2 < rb0.s3) mask |= 2u;
+        if (rb0.s1 < rb0.s2) scan4<WINDOW, true>(g, w, rb0.s1, rb0.s2, qx, qy, qz, hit);
+        if (rb0.s1 + 4 < rb0.s2) {
+            if (hit.d2 > 0.0f) mask |= 1u << 10;
+            else hit.lb2 = 0.0f; // the rest of the cell is not examined
+        }
+        // a range that is not queued because its gap is too large bounds the runner-up by that gap
+        if (rb0.s0 < rb0.s1) {
+            if (G.gxm2 * 0.998f < hit.d2) mask |= 1u;
+            else hit.lb2 = fminf(hit.lb2, G.gxm2);
+        }
+        if (rb0.s2 < rb0.s3) {
+            if (G.gxp2 * 0.998f < hit.d2) mask |= 2u;
+            else hit.lb2 = fminf(hit.lb2, G.gxp2);
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const bool inside = (unsigned)(G.cy + row_dy(k)) < (unsigned)ny && (unsigned)(G.cz + row_dz(k)) < (unsigned)nz;
-            if (inside && row_gap2(G, k) * 0.998f < hit.d2) mask |= 4u << k;
+            const float gap2 = row_gap2(G, k);
+            if (inside) {
+                if (gap2 * 0.998f < hit.d2) mask |= 4u << k;
+                else hit.lb2 = fminf(hit.lb2, gap2);
+            }
         }
     }
     ws->best[lane] = pack_hit(hit.d2, hit.j);
+    ws->lb2[lane] = __float_as_uint(hit.lb2);
     ws->q[lane] = make_float4(qx, qy, qz, 0.0f);
     int total = 0;
 #pragma unroll
@@ -379,16 +404,21 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
             const float cur = __uint_as_float((uint32_t)(__atomic_load_n(&ws->best[owner], __ATOMIC_RELAXED) >> 32));
             const bool own_row = t < 2 || t == 10;
             const float g2 = own_row ? (t == 0 ? G.gxm2 : (t == 1 ? G.gxp2 : 0.0f)) : row_gap2(G, t - 2);
+            float bound = g2; // what this task contributes to the owner's runner-up bound
             if (g2 * 0.998f < cur) {
                 uint32_t a, b;
+                bound = 3.0e38f;
                 if (own_row) {
                     const RowBounds rb = ws->rb0[owner];
                     a = t == 0 ? rb.s0 : (t == 1 ? rb.s2 : rb.s1 + 4);
                     b = t == 0 ? rb.s1 : (t == 1 ? rb.s3 : rb.s2);
                 } else {
                     const RowBounds rb = load_row_bounds(g, ((size_t)(G.cz + row_dz(t - 2)) * ny + (G.cy + row_dy(t - 2))) * nx + G.cx);
-                    a = (g2 + G.gxm2) * 0.998f < cur ? rb.s0 : rb.s1;
-                    b = (g2 + G.gxp2) * 0.998f < cur ? rb.s3 : rb.s2;
+                    const bool xm = (g2 + G.gxm2) * 0.998f < cur, xp = (g2 + G.gxp2) * 0.998f < cur;
+                    a = xm ? rb.s0 : rb.s1;
+                    b = xp ? rb.s3 : rb.s2;
+                    if (!xm && rb.s0 < rb.s1) bound = g2 + G.gxm2;
+                    if (!xp && rb.s2 < rb.s3) bound = fminf(bound, g2 + G.gxp2);
                 }
                 NNHit h;
                 // ties with the best this task started from are reported too (the packed minimum
@@ -396,9 +426,16 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
                 h.d2 = cur < thr ? __uint_as_float(__float_as_uint(cur) + 1u) : thr;
                 h.j = -1;
                 h.px = h.py = h.pz = 0.0f;
-                scan_range<WINDOW>(g, w, a, b, Q.x, Q.y, Q.z, h);
-                if (h.j >= 0) atomicMin(&ws->best[owner], pack_hit(h.d2, h.j));
+                h.lb2 = 3.0e38f;
+                scan_range<WINDOW, true>(g, w, a, b, Q.x, Q.y, Q.z, h);
+                bound = fminf(bound, h.lb2);
+                if (h.j >= 0) { // whichever of (previous best, this candidate) loses is a runner-up
+                    const unsigned long long mine = pack_hit(h.d2, h.j);
+                    const unsigned long long old = atomicMin(&ws->best[owner], mine);
+                    bound = fminf(bound, __uint_as_float((uint32_t)((old > mine ? old : mine) >> 32)));
+                }
             }
+            atomicMin(&ws->lb2[owner], __float_as_uint(bound));
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -406,6 +443,7 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
     if (valid) {
         const unsigned long long m = ws->best[lane];
         const int j = (int)(uint32_t)m;
+        hit.lb2 = __uint_as_float(ws->lb2[lane]);
         if (j != hit.j) { // a task found something better: fetch the winner's coordinates
             const float4 p = g.pts[j];
             hit.d2 = __uint_as_float((uint32_t)(m >> 32));
@@ -426,7 +464,13 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
         if (cz - 1 > 0) mface = fminf(mface, (gz - (float)(cz - 1)) * h);
         if (cz + 1 < nz - 1) mface = fminf(mface, ((float)(cz + 2) - gz) * h);
         const float mm = fmaxf(mface, 0.0f) * 0.999f;
-        if (mface < 3.0e38f && !(hit.d2 <= mm * mm)) nn_rings<WINDOW>(g, w, qx, qy, qz, 2, hit);
+        if (mface < 3.0e38f) {
+            hit.lb2 = fminf(hit.lb2, mm * mm); // nothing outside the 27 cells is closer than their boundary
+            if (!(hit.d2 <= mm * mm)) {
+                nn_rings<WINDOW>(g, w, qx, qy, qz, 2, hit);
+                hit.lb2 = 0.0f; // no bound kept for the per-lane rings
+            }
+        }
     }
     return hit;
 }

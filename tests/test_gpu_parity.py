@@ -453,3 +453,37 @@ def test_query_order_is_free(api, ctx, synth, small_world, mode):
     icp.set_source_batch(np.stack([s[rng.permutation(len(s))] for s in scans]))
     for a, b in zip(out["cell", False][0], icp.align_batch(mode)):
         assert a["n_corr"] == b["n_corr"] and np.abs(a["T64"] - b["T64"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("mode", ["o3d_p2p", "p2plane"])
+def test_nn_reuse_is_exact(api, ctx, synth, small_world, mode):
+    """Neighbour reuse (sf_icp_set_nn_reuse) skips the search of a query whose neighbour provably
+    cannot have changed.  The registration must be bit-identical with it on and off — with and
+    without a map window, for cell-ordered and as-given queries, for scans that start far away,
+    contain NaNs or partly miss the map."""
+    m = small_world["map"]
+    mp = api.Map(ctx, api.Cloud(ctx, m), 0.25)
+    mp.estimate_normals(0.25)
+    scans = np.stack([synth.make_scan(m, 6000, scan_id=s)[0] for s in range(4)])
+    scans[1, ::53] = np.nan
+    scans[2, :2000] += np.float32(30.0)                              # a third of the scan is nowhere near the map
+    inits = np.stack([np.eye(4), np.eye(4), np.eye(4), synth.make_T((0.4, -0.2, 0.1), (0.0, 0.0, 1.5))])
+    for window in (False, True):
+        if window:
+            mp.window_sphere([0.0, 0.0, 0.0], 4.0)
+        else:
+            mp.window_none()
+        for order in ("as_given", "cell"):
+            out = []
+            for reuse in (False, True):
+                icp = api.Icp(ctx, 0.5, 25, 0.05, 1e-5)
+                icp.set_target(mp)
+                icp.set_query_order(order)
+                icp.set_nn_reuse(reuse)
+                icp.set_source_batch(scans)
+                icp.set_initial_batch(inits)
+                out.append(icp.align_batch(mode))
+            for a, b in zip(*out):
+                assert a["n_corr"] == b["n_corr"] and a["iterations"] == b["iterations"] and a["flags"] == b["flags"]
+                assert np.array_equal(a["T64"], b["T64"]) and a["rmse"] == b["rmse"] and a["fitness"] == b["fitness"]
+    mp.window_none()
