@@ -431,7 +431,7 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
 template <int MODE, bool WINDOW, bool SHARD>
 __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                                 int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks,
-                                                const uint32_t *__restrict__ own_off, float4 *__restrict__ qcache, int32_t *__restrict__ jcache)
+                                                const uint32_t *__restrict__ own_off, float4 *__restrict__ qcache, int64_t cache_n)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in launch order, so
@@ -467,30 +467,35 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
         valid = !SHARD || (qx >= xlo && qx < xhi);
     }
     // Neighbour reuse with an exactness certificate.  The last full search of this query (at position
-    // c.xyz) found neighbour jc and proved every OTHER map point at least c.w away.  The query has
-    // moved by delta since; if |q - p_jc| < c.w - delta (triangle inequality, with a rounding margin)
-    // no other point can be nearer, so the search would return jc again -- it is skipped, the
-    // result is bit-identical.  ICP steps shrink geometrically, so after the first few iterations
-    // whole waves certify; a wave with any lane left runs the search for just those lanes.
+    // c0.xyz) found neighbour c1 = (point, index) and proved every OTHER map point at least c0.w
+    // away.  The query has moved by delta since; if |q - p| < c0.w - delta (triangle inequality, with
+    // a rounding margin) no other point can be nearer, so the search would return the same
+    // neighbour -- it is skipped, the result is bit-identical.  ICP steps shrink geometrically, so
+    // after the first few iterations whole waves certify (and then read their pair -- neighbour and
+    // normal -- from three coalesced float4 streams instead of gathering it); a wave with any lane
+    // left runs the search for just those lanes.
     sf::NNHit hit;
     hit.d2 = thr;
     hit.j = -1;
     hit.px = hit.py = hit.pz = 0.0f;
     hit.lb2 = 0.0f;
+    float4 tn = make_float4(0.f, 0.f, 0.f, 0.f); // the neighbour's normal (MODE 2)
     bool need = valid;
     if (qcache && valid) {
-        const float4 c = qcache[o];
-        const int32_t jc = jcache[o];
-        if (c.w > 0.0f) {
-            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (jc >= 0) p = g.pts[jc];
-            const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-            const float reach = c.w * 0.9999f - sqrtf(dx * dx + dy * dy + dz * dz) * 1.0001f - 1.0e-6f;
+        const float4 c0 = qcache[o];
+        if (c0.w > 0.0f) {
+            const float4 c1 = qcache[(size_t)cache_n + o];
+            const int32_t jc = __float_as_int(c1.w);
+            const float dx = qx - c0.x, dy = qy - c0.y, dz = qz - c0.z;
+            const float reach = c0.w * 0.9999f - sqrtf(dx * dx + dy * dy + dz * dz) * 1.0001f - 1.0e-6f;
             if (jc >= 0) {
-                const float d2n = sf::l2_simple(qx, qy, qz, p.x, p.y, p.z);
+                const float d2n = sf::l2_simple(qx, qy, qz, c1.x, c1.y, c1.z);
                 if (sqrtf(d2n) * 1.0001f + 1.0e-6f < reach) {
                     need = false;
-                    if (d2n < thr) { hit.d2 = d2n; hit.j = jc; hit.px = p.x; hit.py = p.y; hit.pz = p.z; }
+                    if (d2n < thr) {
+                        hit.d2 = d2n; hit.j = jc; hit.px = c1.x; hit.py = c1.y; hit.pz = c1.z;
+                        if (MODE == 2) tn = qcache[2 * (size_t)cache_n + o];
+                    }
                 }
             } else if (sqrtf(thr) * 1.0001f + 1.0e-6f < reach) {
                 need = false; // still nothing within the acceptance radius
@@ -503,9 +508,12 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
         const sf::NNHit h = sf::nn_search_wave<WINDOW>(g, w, need, qx, qy, qz, thr, &nn_ws[threadIdx.x >> 6]);
         if (need) {
             hit = h;
+            // only the winner's normal is fetched after the search; its coordinates come in registers
+            if (MODE == 2 && h.j >= 0) tn = g.nrm[h.j];
             if (qcache) {
                 qcache[o] = make_float4(qx, qy, qz, sqrtf(h.lb2));
-                jcache[o] = h.j;
+                qcache[(size_t)cache_n + o] = make_float4(h.px, h.py, h.pz, __int_as_float(h.j));
+                if (MODE == 2) qcache[2 * (size_t)cache_n + o] = tn;
             }
         }
     }
@@ -514,9 +522,6 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
     __shared__ double stage[BLK / 64][32];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool ok = hit.j >= 0;
-    // only the winner's normal is fetched after the search; its coordinates come in registers
-    float4 tn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok && MODE == 2) tn = g.nrm[hit.j];
     // lanes without a correspondence contribute exact zeros: e = 0 and n = 0 zero every product
     const double wgt = ok ? 1.0 : 0.0;
     const double tx = ok ? (double)hit.px : 0.0, ty = ok ? (double)hit.py : 0.0, tz = ok ? (double)hit.pz : 0.0;
@@ -1067,7 +1072,8 @@ struct sf_icp {
     // source
     sf::DevBuf X0, X;        // SoA: x[B*n], y[B*n], z[B*n]
     sf::DevBuf X0r;          // the same points as float4 records (gather source of the query ordering)
-    sf::DevBuf qcache, jcache; // neighbour reuse: position / runner-up bound (float4) and neighbour (int32) of each query's last full search
+    sf::DevBuf qcache;       // neighbour reuse, three float4 arrays of cache_n entries: (query position at its last full search, runner-up bound), (neighbour, its index), (neighbour's normal)
+    int64_t cache_n = 0;
     bool reuse = true;       // sf_icp_set_nn_reuse
     sf::DevBuf Xq, qkeys, qkeys2, qidx, qidx2; // cell-ordered copy of X0 and the sort's buffers
     int order = SF_ORDER_AUTO;
@@ -1145,9 +1151,9 @@ int reuse_reset(sf_icp *icp, int64_t count)
 {
     if (!icp->reuse) return SF_OK;
     const size_t c = (size_t)std::max<int64_t>(count, 1);
-    SF_TRY(icp->qcache.reserve(sizeof(float4) * c));
-    SF_TRY(icp->jcache.reserve(sizeof(int32_t) * c));
-    SF_HIP(hipMemsetAsync(icp->qcache.p, 0, sizeof(float4) * c, icp->ctx->stream));
+    SF_TRY(icp->qcache.reserve(sizeof(float4) * 3 * c));
+    icp->cache_n = (int64_t)c;
+    SF_HIP(hipMemsetAsync(icp->qcache.p, 0, sizeof(float4) * c, icp->ctx->stream)); // the bounds (first array) only
     return SF_OK;
 }
 
@@ -1269,7 +1275,7 @@ void launch_nn_red(sf_icp *icp, bool sharded = false)
     const bool win = m->window.kind != 0;
 #define SF_LAUNCH_NNRED(W, S)                                                                                                                                    \
     hipLaunchKernelGGL((k_nn_red<MODE, W, S>), grid, blk, 0, s, m->grid, m->window, x, y, z, (int)icp->n, st, thr, icp->xlo, icp->xhi, part, nb, \
-                       icp->own_off.as<uint32_t>(), icp->reuse ? icp->qcache.as<float4>() : nullptr, icp->jcache.as<int32_t>())
+                       icp->own_off.as<uint32_t>(), icp->reuse ? icp->qcache.as<float4>() : nullptr, icp->cache_n)
     if (win && sharded) SF_LAUNCH_NNRED(true, true);
     else if (win) SF_LAUNCH_NNRED(true, false);
     else if (sharded) SF_LAUNCH_NNRED(false, true);
@@ -1397,7 +1403,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     (void)e;
     if (icp->graph_exec) { e = hipGraphExecDestroy(icp->graph_exec); (void)e; }
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
-    icp->X0.release(); icp->X0r.release(); icp->qcache.release(); icp->jcache.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
+    icp->X0.release(); icp->X0r.release(); icp->qcache.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
     icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
