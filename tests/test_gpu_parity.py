@@ -487,3 +487,53 @@ def test_nn_reuse_is_exact(api, ctx, synth, small_world, mode):
                 assert a["n_corr"] == b["n_corr"] and a["iterations"] == b["iterations"] and a["flags"] == b["flags"]
                 assert np.array_equal(a["T64"], b["T64"]) and a["rmse"] == b["rmse"] and a["fitness"] == b["fitness"]
     mp.window_none()
+
+
+def test_nn_reuse_fuzz(api, ctx, synth):
+    """Randomised scenes for the neighbour-reuse certificate: clustered and duplicated map points,
+    points on cell faces, sparse maps, several cell sizes, large and tiny start offsets — the
+    registration must not depend on the switch in a single bit."""
+    rng = np.random.default_rng(77)
+    for trial in range(24):
+        kind = trial % 4
+        n_map = int(rng.integers(2_000, 60_000))
+        if kind == 0:                                   # uniform volume
+            m = rng.uniform(-6, 6, (n_map, 3))
+        elif kind == 1:                                 # clusters + exact duplicates
+            c = rng.uniform(-6, 6, (40, 3))
+            m = c[rng.integers(0, 40, n_map)] + rng.normal(0, 0.15, (n_map, 3))
+            m[::7] = m[1::7][: len(m[::7])]
+        elif kind == 2:                                 # points snapped to a lattice: ties and cell faces
+            m = np.round(rng.uniform(-6, 6, (n_map, 3)) * 8) / 8
+        else:                                           # planes
+            m = rng.uniform(-6, 6, (n_map, 3))
+            m[: n_map // 2, 2] = 0.0
+            m[n_map // 2:, 0] = 2.0
+        m = m.astype(np.float32)
+        cell = float(rng.choice([0.0, 0.15, 0.25, 0.5]))
+        mp = api.Map(ctx, api.Cloud(ctx, m), cell)
+        mp.estimate_normals(0.4)
+        n_scan = int(rng.integers(300, 5000))
+        scans, inits = [], []
+        for s in range(3):
+            T = synth.make_T(rng.normal(0, 0.1 if s else 0.01, 3), rng.normal(0, 1.0 if s else 0.05, 3))
+            idx = rng.integers(0, len(m), n_scan)
+            p = m[idx].astype(np.float64) + rng.normal(0, 0.02, (n_scan, 3))
+            Ti = np.linalg.inv(T)
+            scans.append((p @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32))
+            inits.append(np.eye(4))
+        scans = np.stack(scans)
+        for mode in ("p2plane", "o3d_p2p"):
+            thr = float(rng.choice([0.3, 0.5, 1.0]))
+            res = []
+            for reuse in (False, True):
+                icp = api.Icp(ctx, thr, 15, 0.05, 1e-5)
+                icp.set_target(mp)
+                icp.set_nn_reuse(reuse)
+                icp.set_query_order("cell" if trial % 2 else "as_given")
+                icp.set_source_batch(scans)
+                icp.set_initial_batch(np.stack(inits))
+                res.append(icp.align_batch(mode))
+            for a, b in zip(*res):
+                assert a["n_corr"] == b["n_corr"] and a["iterations"] == b["iterations"] and a["flags"] == b["flags"], (trial, mode)
+                assert np.array_equal(a["T64"], b["T64"], equal_nan=True) and (a["rmse"] == b["rmse"] or (np.isnan(a["rmse"]) and np.isnan(b["rmse"]))), (trial, mode)
