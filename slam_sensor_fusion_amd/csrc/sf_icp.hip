@@ -1525,6 +1525,7 @@ extern "C" int sf_icp_use_graph(sf_icp *icp, int on)
 extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
 {
     SF_TRY(check_ready(icp, mode));
+    SF_CHECK(!icp->shard, SF_ERR_STATE, "a sharded alignment needs the exchange between its halves: use sf_icp_step_begin / sf_icp_step_end");
     SF_HIP(hipSetDevice(icp->ctx->device));
     hipStream_t s = icp->ctx->stream;
     icp->last_mode = mode;

@@ -58,3 +58,17 @@ def test_empty_and_tiny_inputs(api, ctx, small_world):
     icp.set_source(nan_scan)
     r = icp.align("p2plane")
     assert r["n_corr"] == np.isfinite(nan_scan).all(1).sum() and np.isfinite(r["T64"]).all()
+
+
+def test_sharded_icp_needs_the_step_api(api, ctx, small_world):
+    mp = api.Map(ctx, api.Cloud(ctx, small_world["map"]), 0.25)
+    icp = api.Icp(ctx, 0.5, 10, 0.05, 1e-5)
+    icp.set_target(mp)
+    icp.set_source(small_world["scan"][:500])
+    icp.set_shard(-1.0, 1.0)
+    with pytest.raises(api.SlamFusionError, match="sharded"):
+        icp.align("o3d_p2p")
+    with pytest.raises(api.SlamFusionError):
+        icp.step_begin("o3d_p2p", 3)
+    with pytest.raises(api.SlamFusionError):
+        icp.set_shard_margin(0.0)
