@@ -241,7 +241,10 @@ __device__ __forceinline__ int ldlt6(const double (&A)[36], const double (&b)[6]
 // R = Rz(v2) Ry(v1) Rx(v0), t = v[3:6] (Open3D TransformVector6dToMatrix4d)
 __device__ __forceinline__ void vec6_to_mat4(const double (&v)[6], double (&T)[16])
 {
-    const double ca = cos(v[0]), sa = sin(v[0]), cb = cos(v[1]), sb = sin(v[1]), cg = cos(v[2]), sg = sin(v[2]);
+    double ca, sa, cb, sb, cg, sg; // one range reduction per angle
+    sincos(v[0], &sa, &ca);
+    sincos(v[1], &sb, &cb);
+    sincos(v[2], &sg, &cg);
     const double R[9] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa,
                          sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa,
                          -sb, cb * sa, cb * ca};
