@@ -460,8 +460,18 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
     float qx = 0.f, qy = 0.f, qz = 0.f;
     bool valid = false;
     size_t o = 0;
+    // once the alignment has searched (every entry is then either written or still zero from the
+    // reset) the three cache streams are requested together with the scan point: one round trip
+    // for a verifying wave instead of four dependent ones
+    const bool cache_live = qcache != nullptr && S->n_research > 0;
+    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0;
     if (slot < n_live) {
         o = SHARD ? (size_t)own_off[b] + (size_t)slot : (size_t)b * n + (size_t)slot;
+        if (cache_live) {
+            c0 = qcache[o];
+            c1 = qcache[(size_t)cache_n + o];
+            if (MODE == 2) c2 = qcache[2 * (size_t)cache_n + o];
+        }
         const double x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
         sx = S->T[0] * x0 + S->T[1] * y0 + S->T[2] * z0 + S->T[3];
         sy = S->T[4] * x0 + S->T[5] * y0 + S->T[6] * z0 + S->T[7];
@@ -484,10 +494,8 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
     hit.lb2 = 0.0f;
     float4 tn = make_float4(0.f, 0.f, 0.f, 0.f); // the neighbour's normal (MODE 2)
     bool need = valid;
-    if (qcache && valid) {
-        const float4 c0 = qcache[o];
+    if (valid) {
         if (c0.w > 0.0f) {
-            const float4 c1 = qcache[(size_t)cache_n + o];
             const int32_t jc = __float_as_int(c1.w);
             const float dx = qx - c0.x, dy = qy - c0.y, dz = qz - c0.z;
             const float reach = c0.w * 0.9999f - sqrtf(dx * dx + dy * dy + dz * dz) * 1.0001f - 1.0e-6f;
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
                     need = false;
                     if (d2n < thr) {
                         hit.d2 = d2n; hit.j = jc; hit.px = c1.x; hit.py = c1.y; hit.pz = c1.z;
-                        if (MODE == 2) tn = qcache[2 * (size_t)cache_n + o];
+                        tn = c2;
                     }
                 }
             } else if (sqrtf(thr) * 1.0001f + 1.0e-6f < reach) {
