@@ -428,34 +428,24 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
 // ------------------------------------------------------------------ fused transform + NN + accumulate
 // MODE 1: point-to-point record (17):  n, sum s[3], sum t[3], sum s t^T[9], sum d2
 // MODE 2: point-to-plane record (30):  n, sum r^2, JtJ upper[21], Jtr[6], sum d2
-// One query per lane (grid.x = ceil(n / 256), grid.y = scans in the batch).  The search
-// runs first with nothing else live in registers; the pair's contribution is formed
-// afterwards and goes straight into the wave reduction.
+// QPL queries per lane (grid.x = ceil(n / (256 * QPL)), grid.y = scans in the batch), one after the
+// other: neighbour (reuse certificate or search), then the contributions of the lane's pairs are
+// added and go through ONE wave reduction.  Measured: QPL = 2 (half the reductions and slab rows,
+// 87 instead of 80 VGPR) is within 1 % of QPL = 1 at 1, 8 and 32 scans in flight -- the simpler one stays.
+constexpr int QPL = 1;
+
+struct LanePair {
+    double sx, sy, sz; // the transformed scan point (float64)
+    float px, py, pz;  // its neighbour
+    float4 tn;         // the neighbour's normal (MODE 2)
+    bool ok;
+};
+
 template <int MODE, bool WINDOW, bool SHARD>
-__global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
-                                                int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks,
-                                                const uint32_t *__restrict__ own_off, float4 *__restrict__ qcache, int64_t cache_n)
+__device__ __forceinline__ LanePair nn_pair(const SfGrid &g, const SfWindow &w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
+                                            int n, int b, const IcpState *S, float thr, float xlo, float xhi, const uint32_t *__restrict__ own_off,
+                                            float4 *__restrict__ qcache, int64_t cache_n, int slot, int n_live, sf::WaveNN *ws)
 {
-    constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
-    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in launch order, so
-    // linear id L runs on XCD L % 8.  Each XCD sweeps its own CONTIGUOUS eighth of the chunks
-    // (chunk = 256 consecutive queries of a scan), all scans of the batch adjacent in time: with
-    // cell-ordered queries, chunk c of every scan covers about the same stretch of the map (to
-    // within a chunk or so), so neighbouring chunks must meet in the same L2.  grid.x is padded
-    // to a multiple of 8.
-    const int L = blockIdx.y * gridDim.x + blockIdx.x;
-    const int kk = L >> 3;
-    const int b = kk % (int)gridDim.y;
-    const int bx = (L & 7) * ((int)gridDim.x >> 3) + kk / (int)gridDim.y;
-    if (bx >= nblocks) return;
-    const IcpState *S = st + b;
-    if (S->done) return;
-    const int slot = bx * BLK + threadIdx.x;
-    // sharded: X0x/y/z are this rank's compact arrays of owned-query candidates (slab widened by
-    // the margin at the pose the arrays were built at, cell-ordered, scan b at [own_off[b], own_off[b+1]));
-    // the exact slab predicate is still applied per lane
-    const int n_live = SHARD ? (int)(own_off[b + 1] - own_off[b]) : n;
-    if (SHARD && bx * BLK >= n_live) return; // k_reduce_only reads only the rows that exist
     double sx = 0, sy = 0, sz = 0;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     bool valid = false;
@@ -514,9 +504,8 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
         }
     }
     // every lane takes part in the search (lanes without a query still execute other lanes' tasks)
-    __shared__ sf::WaveNN nn_ws[BLK / 64];
     if (__ballot(need) != 0ull) {
-        const sf::NNHit h = sf::nn_search_wave<WINDOW>(g, w, need, qx, qy, qz, thr, &nn_ws[threadIdx.x >> 6]);
+        const sf::NNHit h = sf::nn_search_wave<WINDOW>(g, w, need, qx, qy, qz, thr, ws);
         if (need) {
             hit = h;
             // only the winner's normal is fetched after the search; its coordinates come in registers
@@ -528,68 +517,125 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
             }
         }
     }
-    // contribution of this lane's pair, reduced over the wave in two halves of 16 values
-    // (keeps the live registers low enough for 4+ waves per SIMD), staged per wave in LDS
+    LanePair P;
+    P.sx = sx; P.sy = sy; P.sz = sz;
+    P.px = hit.px; P.py = hit.py; P.pz = hit.pz;
+    P.tn = tn;
+    P.ok = hit.j >= 0;
+    return P;
+}
+
+// lanes without a correspondence contribute exact zeros: e = 0 and n = 0 zero every product
+struct PairTerms { double wgt, ux, uy, uz, tx, ty, tz, ex, ey, ez, d2, r; double J[6]; };
+template <int MODE>
+__device__ __forceinline__ PairTerms pair_terms(const LanePair &P)
+{
+    PairTerms t;
+    const bool ok = P.ok;
+    t.wgt = ok ? 1.0 : 0.0;
+    t.tx = ok ? (double)P.px : 0.0; t.ty = ok ? (double)P.py : 0.0; t.tz = ok ? (double)P.pz : 0.0;
+    t.ex = ok ? P.sx - t.tx : 0.0; t.ey = ok ? P.sy - t.ty : 0.0; t.ez = ok ? P.sz - t.tz : 0.0;
+    t.d2 = t.ex * t.ex + t.ey * t.ey + t.ez * t.ez;
+    t.ux = ok ? P.sx : 0.0; t.uy = ok ? P.sy : 0.0; t.uz = ok ? P.sz : 0.0; // a non-finite dead query must not turn 0 * s into NaN
+    if (MODE == 2) {
+        const double nx = P.tn.x, ny = P.tn.y, nz = P.tn.z; // zero for dead lanes -> J = 0, r = 0
+        t.r = t.ex * nx + t.ey * ny + t.ez * nz;
+        t.J[0] = t.uy * nz - t.uz * ny; t.J[1] = t.uz * nx - t.ux * nz; t.J[2] = t.ux * ny - t.uy * nx;
+        t.J[3] = nx; t.J[4] = ny; t.J[5] = nz;
+    } else {
+        t.r = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) t.J[a] = 0.0;
+    }
+    return t;
+}
+
+// the 32 record slots of one pair, half h (0: slots 0..15, 1: slots 16..31), added to v
+template <int MODE>
+__device__ __forceinline__ void add_half(const PairTerms &t, int h, double (&v)[16])
+{
+    if (MODE == 1) {
+        if (h == 0) {
+            v[0] += t.wgt;
+            v[1] += t.ux; v[2] += t.uy; v[3] += t.uz;
+            v[4] += t.tx; v[5] += t.ty; v[6] += t.tz;
+            v[7] += t.ux * t.tx; v[8] += t.ux * t.ty; v[9] += t.ux * t.tz;
+            v[10] += t.uy * t.tx; v[11] += t.uy * t.ty; v[12] += t.uy * t.tz;
+            v[13] += t.uz * t.tx; v[14] += t.uz * t.ty; v[15] += t.uz * t.tz;
+        } else {
+            v[0] += t.d2;
+        }
+    } else {
+        // record[0..15] = n, sum r^2, JtJ (0,0) (0,1) .. (0,5) (1,1) .. (1,5) (2,2) (2,3) (2,4)
+        // record[16..31] = JtJ (2,5) (3,3) .. (5,5), Jtr[6], sum d2, 0, 0
+        if (h == 0) { v[0] += t.wgt; v[1] += t.r * t.r; }
+        int k = 2;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int c = a; c < 6; ++c) {
+                if (h == 0 && k < 16) v[k] += t.J[a] * t.J[c];
+                if (h == 1 && k >= 16) v[k - 16] += t.J[a] * t.J[c];
+                ++k;
+            }
+        }
+        if (h == 1) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) v[7 + a] += t.J[a] * t.r;
+            v[13] += t.d2;
+        }
+    }
+}
+
+template <int MODE, bool WINDOW, bool SHARD>
+__global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
+                                                int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks,
+                                                const uint32_t *__restrict__ own_off, float4 *__restrict__ qcache, int64_t cache_n)
+{
+    constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in launch order, so
+    // linear id L runs on XCD L % 8.  Each XCD sweeps its own CONTIGUOUS eighth of the chunks
+    // (chunk = 256 * QPL consecutive queries of a scan), all scans of the batch adjacent in time:
+    // with cell-ordered queries, chunk c of every scan covers about the same stretch of the map (to
+    // within a chunk or so), so neighbouring chunks must meet in the same L2.  grid.x is padded
+    // to a multiple of 8.
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int kk = L >> 3;
+    const int b = kk % (int)gridDim.y;
+    const int bx = (L & 7) * ((int)gridDim.x >> 3) + kk / (int)gridDim.y;
+    if (bx >= nblocks) return;
+    const IcpState *S = st + b;
+    if (S->done) return;
+    // sharded: X0x/y/z are this rank's compact arrays of owned-query candidates (slab widened by
+    // the margin at the pose the arrays were built at, cell-ordered, scan b at [own_off[b], own_off[b+1]));
+    // the exact slab predicate is still applied per lane
+    const int n_live = SHARD ? (int)(own_off[b + 1] - own_off[b]) : n;
+    if (SHARD && bx * (BLK * QPL) >= n_live) return; // k_reduce_only reads only the rows that exist
+    __shared__ sf::WaveNN nn_ws[BLK / 64];
     __shared__ double stage[BLK / 64][32];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool ok = hit.j >= 0;
-    // lanes without a correspondence contribute exact zeros: e = 0 and n = 0 zero every product
-    const double wgt = ok ? 1.0 : 0.0;
-    const double tx = ok ? (double)hit.px : 0.0, ty = ok ? (double)hit.py : 0.0, tz = ok ? (double)hit.pz : 0.0;
-    const double ex = ok ? sx - tx : 0.0, ey = ok ? sy - ty : 0.0, ez = ok ? sz - tz : 0.0;
-    const double d2 = ex * ex + ey * ey + ez * ez;
-    if (MODE == 1) {
-        const double ux = ok ? sx : 0.0, uy = ok ? sy : 0.0, uz = ok ? sz : 0.0; // s, zeroed for dead lanes
+    PairTerms T[QPL];
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) {
+        const int slot = bx * (BLK * QPL) + u * BLK + (int)threadIdx.x;
+        const LanePair P = nn_pair<MODE, WINDOW, SHARD>(g, w, X0x, X0y, X0z, n, b, S, thr, xlo, xhi, own_off, qcache, cache_n, slot, n_live, &nn_ws[wv]);
+        T[u] = pair_terms<MODE>(P);
+    }
+    // the lane's pairs added, reduced over the wave in two halves of 16 values (keeps the live
+    // registers low enough for 4+ waves per SIMD), staged per wave in LDS
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
         double v[16];
-        v[0] = wgt;
-        v[1] = ux; v[2] = uy; v[3] = uz;
-        v[4] = tx; v[5] = ty; v[6] = tz;
-        v[7] = ux * tx; v[8] = ux * ty; v[9] = ux * tz;
-        v[10] = uy * tx; v[11] = uy * ty; v[12] = uy * tz;
-        v[13] = uz * tx; v[14] = uz * ty; v[15] = uz * tz;
-        const double t0 = wave_reduce_16(v);
-        const double t1 = wave_reduce_1(d2);
-        if ((lane & 3) == 0) stage[wv][lane >> 2] = t0;
-        if (lane == 0) stage[wv][16] = t1;
-    } else {
-        const double nx = tn.x, ny = tn.y, nz = tn.z;  // zero for dead lanes -> J = 0, r = 0
-        const double r = ex * nx + ey * ny + ez * nz;
-        const double ux = ok ? sx : 0.0, uy = ok ? sy : 0.0, uz = ok ? sz : 0.0; // a non-finite dead query must not turn 0 * s into NaN
-        const double J[6] = {uy * nz - uz * ny, uz * nx - ux * nz, ux * ny - uy * nx, nx, ny, nz};
-        {   // record[0..15] = n, sum r^2, JtJ (0,0) (0,1) .. (0,5) (1,1) .. (1,5) (2,2) (2,3) (2,4)
-            double v[16];
-            v[0] = wgt;
-            v[1] = r * r;
-            int k = 2;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
+        for (int k = 0; k < 16; ++k) v[k] = 0.0;
 #pragma unroll
-                for (int c = a; c < 6; ++c) {
-                    if (k < 16) v[k] = J[a] * J[c];
-                    ++k;
-                }
-            }
+        for (int u = 0; u < QPL; ++u) add_half<MODE>(T[u], h, v);
+        if (MODE == 1 && h == 1) {
+            const double t1 = wave_reduce_1(v[0]);
+            if (lane == 0) stage[wv][16] = t1;
+        } else {
             const double t0 = wave_reduce_16(v);
-            if ((lane & 3) == 0) stage[wv][lane >> 2] = t0;
-        }
-        {   // record[16..31] = JtJ (2,5) (3,3) .. (5,5), Jtr[6], sum d2, 0, 0
-            double v[16];
-            int k = 2;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                for (int c = a; c < 6; ++c) {
-                    if (k >= 16) v[k - 16] = J[a] * J[c];
-                    ++k;
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < 6; ++a) v[7 + a] = J[a] * r;
-            v[13] = d2;
-            v[14] = 0.0;
-            v[15] = 0.0;
-            const double t1 = wave_reduce_16(v);
-            if ((lane & 3) == 0) stage[wv][16 + (lane >> 2)] = t1;
+            if ((lane & 3) == 0) stage[wv][16 * h + (lane >> 2)] = t0;
         }
     }
     __syncthreads();
@@ -909,7 +955,7 @@ __global__ __launch_bounds__(RBLK) void k_reduce_only(IcpState *__restrict__ st,
         if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = 0.0;
         return;
     }
-    const int rows = own_off ? (int)((own_off[b + 1] - own_off[b] + BLK - 1) / BLK) : nblocks; // sharded: workgroups beyond the owned queries wrote nothing
+    const int rows = own_off ? (int)((own_off[b + 1] - own_off[b] + BLK * QPL - 1) / (BLK * QPL)) : nblocks; // sharded: workgroups beyond the owned queries wrote nothing
     reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, rows, rec);
     if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = rec[threadIdx.x];
 }
@@ -1102,7 +1148,8 @@ struct sf_icp {
     sf::DevBuf state, d_inits, partials, xchg_own;
     void *xchg = nullptr;
     int64_t xchg_bytes = 0;
-    int nblocks = 0;
+    int nblocks = 0;         // workgroups of 256 points covering a scan (REF_CPP kernels, owned-query compaction)
+    int nblocks_nn = 0;      // k_nn_red workgroups per scan = slab rows (256 * QPL queries each)
     std::vector<IcpState> h_state;
     // sharding
     bool shard = false;
@@ -1210,6 +1257,7 @@ int icp_alloc(sf_icp *icp, int64_t n, int batch)
     SF_TRY(icp->state.reserve(sizeof(IcpState) * (size_t)batch));
     SF_TRY(icp->d_inits.reserve(sizeof(double) * 16 * (size_t)batch));
     icp->nblocks = (int)std::max<int64_t>(1, sf::div_up(n, BLK));
+    icp->nblocks_nn = (int)std::max<int64_t>(1, sf::div_up(n, BLK * QPL));
     SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)REC_STRIDE * (size_t)icp->nblocks * (size_t)batch));
     SF_TRY(icp->xchg_own.reserve(sizeof(double) * REC_STRIDE * (size_t)batch));
     if (icp->batch != batch || icp->inits.size() != (size_t)batch * 16) {
@@ -1275,7 +1323,7 @@ template <int MODE>
 void launch_nn_red(sf_icp *icp, bool sharded = false)
 {
     sf_map *m = icp->map;
-    const int nb = sharded ? icp->own_nblocks : icp->nblocks;
+    const int nb = sharded ? icp->own_nblocks : icp->nblocks_nn;
     const dim3 grid((unsigned)((nb + 7) & ~7), (unsigned)icp->batch), blk(BLK); // see the XCD mapping in k_nn_red
     const float *x = src(icp, 0), *y = src(icp, 1), *z = src(icp, 2);
     const IcpState *st = icp->state.as<IcpState>();
@@ -1315,12 +1363,12 @@ int enqueue_align(sf_icp *icp, int mode)
     if (mode == SF_ICP_O3D_P2P) {
         for (int k = 0; k <= K; ++k) {
             launch_nn_red<1>(icp);
-            hipLaunchKernelGGL(k_reduce_solve<1>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks, n, k, K);
+            hipLaunchKernelGGL(k_reduce_solve<1>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K);
         }
     } else if (mode == SF_ICP_P2PLANE) {
         for (int k = 0; k < K; ++k) {
             launch_nn_red<2>(icp);
-            hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks, n, k, K);
+            hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K);
         }
     } else {
         const int64_t total = icp->n * B;
@@ -1670,7 +1718,7 @@ int shard_build(sf_icp *icp, bool resume)
     }
     const int64_t own = (int64_t)icp->h_own[(size_t)B];
     icp->own_total = own;
-    icp->own_nblocks = (int)std::max<int64_t>(1, sf::div_up((int64_t)maxc, BLK));
+    icp->own_nblocks = (int)std::max<int64_t>(1, sf::div_up((int64_t)maxc, BLK * QPL));
     SF_HIP(hipMemcpyAsync(icp->own_off.p, icp->h_own.data(), sizeof(uint32_t) * (size_t)(B + 1), hipMemcpyHostToDevice, s));
     const size_t cap = (size_t)std::max<int64_t>(own, 1);
     SF_TRY(icp->own_idx.reserve(sizeof(uint32_t) * cap));
@@ -1726,7 +1774,7 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
     }
     double *x = reinterpret_cast<double *>(sf_icp_exchange_ptr(icp, nullptr));
     hipStream_t s = icp->ctx->stream;
-    const int nb = icp->shard ? icp->own_nblocks : icp->nblocks;
+    const int nb = icp->shard ? icp->own_nblocks : icp->nblocks_nn;
     const uint32_t *off = icp->shard ? icp->own_off.as<uint32_t>() : nullptr;
     if (mode == SF_ICP_O3D_P2P) {
         launch_nn_red<1>(icp, icp->shard);
