@@ -116,6 +116,7 @@ struct SfGrid {
     float org[3];      // grid origin (min corner)
     float inv_h;       // 1 / cell
     float h;           // cell size
+    float gap_eps;     // what a computed query-to-cell-face distance may exceed the true one by (float32 rounding of grid coordinates)
     int dim[3];        // cells per axis
     const uint32_t *cell_start; // [ncell + 1]
     const float4 *pts;          // sorted by cell: x, y, z, bitcast(original index)

@@ -186,6 +186,10 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
     for (int d = 0; d < 3; ++d) { G.org[d] = g.org[d]; G.dim[d] = dim[d]; }
     G.inv_h = g.inv_h;
     G.h = (float)h;
+    // |computed grid coordinate - true one| <= 2^-23 * coordinate for the point and for the query, so a
+    // face distance derived from them can be too long by 2^-22 * (largest coordinate) cells; 1.5 x for the
+    // roundings of the gap arithmetic itself.  Every pruning decision of the search subtracts it (sf_nn.hpp).
+    G.gap_eps = 1.5f * 2.384186e-7f * (float)std::max(dim[0], std::max(dim[1], dim[2])) * (float)h;
     G.cell_start = m->cell_start.as<uint32_t>() + 1;
     G.pts = m->pts4.as<float4>();
     G.nrm = nullptr;

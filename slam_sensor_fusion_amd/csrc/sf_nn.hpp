@@ -23,7 +23,11 @@
 // Exactness: after scanning the block of radius R around the query's cell, every
 // unscanned point is at least m = distance(query, block boundary) away; the search stops
 // when best <= m^2 (best starts at the acceptance threshold, so "nothing acceptable
-// outside" ends it too), otherwise the block grows by one ring.
+// outside" ends it too), otherwise the block grows by one ring.  Cells, rows and rings are only
+// skipped when their distance from the query -- computed in float32 grid coordinates, minus
+// SfGrid::gap_eps for the rounding of those coordinates (a point and a query are binned by the
+// same monotone float expression, so the true face distance can be shorter than the computed
+// one by at most 2^-22 x the largest cell coordinate), times 0.998 -- is not below the best.
 // Distance = FLANN L2_Simple in float32: ((dx*dx) + dy*dy) + dz*dz, unfused; strict "<".
 #pragma once
 #include "sf_common.hpp"
@@ -140,6 +144,10 @@ __device__ __forceinline__ void scan_row(const SfGrid &g, const SfWindow &w, con
     if (xp && (gap2yz + gxp2) * 0.998f < hit.d2) scan_range<WINDOW>(g, w, rb.s2, rb.s3, qx, qy, qz, hit);
 }
 
+// a face distance with the rounding slack of the grid coordinates taken off (never negative): the
+// true distance is at least this
+__device__ __forceinline__ float safe_gap(float gap, float eps) { return fmaxf(gap - eps, 0.0f); }
+
 // distance (in cells, >= 0) from grid coordinate gc to the cell interval [c, c+1]
 __device__ __forceinline__ float cell_gap(float gc, int c, int cq)
 {
@@ -182,9 +190,10 @@ __device__ __forceinline__ void nn_rings(const SfGrid &g, const SfWindow &w, flo
                 constexpr uint32_t OYP = 0u | (2u << 2) | (1u << 4) | (1u << 6) | (0u << 8) | (2u << 10) | (0u << 12) | (2u << 14);
                 constexpr uint32_t OZP = 1u | (1u << 2) | (0u << 4) | (2u << 6) | (0u << 8) | (0u << 10) | (2u << 12) | (2u << 14);
                 const float fx = gx - (float)cx, fy = gy - (float)cy, fz = gz - (float)cz;
-                const float gxm = fmaxf(fx, 0.0f) * h, gxp = fmaxf(1.0f - fx, 0.0f) * h;
-                const float gym = fmaxf(fy, 0.0f) * h, gyp = fmaxf(1.0f - fy, 0.0f) * h;
-                const float gzm = fmaxf(fz, 0.0f) * h, gzp = fmaxf(1.0f - fz, 0.0f) * h;
+                const float ge = g.gap_eps;
+                const float gxm = safe_gap(fx * h, ge), gxp = safe_gap((1.0f - fx) * h, ge);
+                const float gym = safe_gap(fy * h, ge), gyp = safe_gap((1.0f - fy) * h, ge);
+                const float gzm = safe_gap(fz * h, ge), gzp = safe_gap((1.0f - fz) * h, ge);
                 const float gxm2 = gxm * gxm, gxp2 = gxp * gxp;
                 const bool xm = cx > 0, xp = cx < nx - 1;
                 auto row_gap2 = [&](int k) -> float {
@@ -234,9 +243,9 @@ __device__ __forceinline__ void nn_rings(const SfGrid &g, const SfWindow &w, flo
                 }
             } else {
                 for (int z = z0; z <= z1; ++z) {
-                    const float rz = cell_gap(gz, z, cz) * h;
+                    const float rz = safe_gap(cell_gap(gz, z, cz) * h, g.gap_eps);
                     for (int y = y0; y <= y1; ++y) {
-                        const float ry = cell_gap(gy, y, cy) * h;
+                        const float ry = safe_gap(cell_gap(gy, y, cy) * h, g.gap_eps);
                         if ((ry * ry + rz * rz) * 0.998f >= hit.d2) continue;
                         const size_t row = ((size_t)z * ny + y) * nx;
                         scan_range<WINDOW>(g, w, g.cell_start[row + x0], g.cell_start[row + x1 + 1], qx, qy, qz, hit);
@@ -254,7 +263,7 @@ __device__ __forceinline__ void nn_rings(const SfGrid &g, const SfWindow &w, flo
         if (cz - R > 0) m = fminf(m, (gz - (float)(cz - R)) * h);
         if (cz + R < nz - 1) m = fminf(m, ((float)(cz + R + 1) - gz) * h);
         if (m >= 3.0e38f) break; // whole grid scanned
-        const float mm = fmaxf(m, 0.0f) * 0.999f;
+        const float mm = safe_gap(m, g.gap_eps) * 0.999f;
         if (hit.d2 <= mm * mm) break;
     }
 }
@@ -311,13 +320,14 @@ __device__ __forceinline__ QueryGeo query_geo(const SfGrid &g, float qx, float q
     G.cz = (int)fminf(fmaxf(floorf(gz), 0.0f), (float)(g.dim[2] - 1));
     const float h = g.h;
     const float fx = gx - (float)G.cx, fy = gy - (float)G.cy, fz = gz - (float)G.cz;
-    const float gxm = fmaxf(fx, 0.0f) * h, gxp = fmaxf(1.0f - fx, 0.0f) * h;
+    const float ge = g.gap_eps;
+    const float gxm = safe_gap(fx * h, ge), gxp = safe_gap((1.0f - fx) * h, ge);
     G.gxm2 = G.cx > 0 ? gxm * gxm : 3.0e38f;
     G.gxp2 = G.cx < g.dim[0] - 1 ? gxp * gxp : 3.0e38f;
-    G.gym = fmaxf(fy, 0.0f) * h;
-    G.gyp = fmaxf(1.0f - fy, 0.0f) * h;
-    G.gzm = fmaxf(fz, 0.0f) * h;
-    G.gzp = fmaxf(1.0f - fz, 0.0f) * h;
+    G.gym = safe_gap(fy * h, ge);
+    G.gyp = safe_gap((1.0f - fy) * h, ge);
+    G.gzm = safe_gap(fz * h, ge);
+    G.gzp = safe_gap((1.0f - fz) * h, ge);
     return G;
 }
 
@@ -463,7 +473,7 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
         if (cy + 1 < ny - 1) mface = fminf(mface, ((float)(cy + 2) - gy) * h);
         if (cz - 1 > 0) mface = fminf(mface, (gz - (float)(cz - 1)) * h);
         if (cz + 1 < nz - 1) mface = fminf(mface, ((float)(cz + 2) - gz) * h);
-        const float mm = fmaxf(mface, 0.0f) * 0.999f;
+        const float mm = safe_gap(mface, g.gap_eps) * 0.999f;
         if (mface < 3.0e38f) {
             hit.lb2 = fminf(hit.lb2, mm * mm); // nothing outside the 27 cells is closer than their boundary
             if (!(hit.d2 <= mm * mm)) {
