@@ -10,8 +10,10 @@
 // ordered by the map cell they fall in under the initial pose (k_query_keys, rocPRIM radix sort,
 // k_gather_queries), so that the scans in flight walk the map together.
 // Per iteration:
-//   k_nn_red        one lane per source point: s = T*x0 (float64), exact grid 1-NN of
-//                   float32(s) (wave-cooperative, sf_nn.hpp), the pair's contribution in
+//   k_nn_red        one lane per source point: s = T*x0 (float64); the neighbour found by the
+//                   point's last search is kept when a bound proved by that search shows it
+//                   cannot have changed (bit-identical result), otherwise exact grid 1-NN of
+//                   float32(s) (wave-cooperative, sf_nn.hpp); the pair's contribution in
 //                   float64, wave64 transposing-butterfly reduce (permlane swaps + DPP) -> LDS
 //                   across the 4 waves -> one partial record per workgroup in a slab (no float
 //                   atomics: bitwise reproducible).  Workgroups are placed XCD-aware: every XCD
