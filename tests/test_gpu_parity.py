@@ -537,3 +537,38 @@ def test_nn_reuse_fuzz(api, ctx, synth):
             for a, b in zip(*res):
                 assert a["n_corr"] == b["n_corr"] and a["iterations"] == b["iterations"] and a["flags"] == b["flags"], (trial, mode)
                 assert np.array_equal(a["T64"], b["T64"], equal_nan=True) and (a["rmse"] == b["rmse"] or (np.isnan(a["rmse"]) and np.isnan(b["rmse"]))), (trial, mode)
+
+
+def test_switches_between_alignments_with_graph_replay(api, ctx, synth, small_world):
+    """One sf_icp object, hipGraph replay on, switches flipped between alignments: the captured
+    launch list carries the neighbour-cache and query-array pointers, so a flip must re-capture."""
+    m = small_world["map"]
+    mp = api.Map(ctx, api.Cloud(ctx, m), 0.25)
+    mp.estimate_normals(0.25)
+    scans = np.stack([synth.make_scan(m, 5000, scan_id=s)[0] for s in range(2)])
+    icp = api.Icp(ctx, 0.5, 15, 0.05, 1e-5)
+    icp.set_target(mp)
+    icp.use_graph(True)
+    icp.set_source_batch(scans)
+    ref = None
+    for reuse, order in [(True, "cell"), (False, "cell"), (True, "cell"), (True, "as_given"), (False, "as_given"), (True, "cell")]:
+        icp.set_nn_reuse(reuse)
+        icp.set_query_order(order)
+        for _ in range(2):
+            r = icp.align_batch("p2plane")
+            key = order
+            if ref is None:
+                ref = {}
+            if key not in ref:
+                ref[key] = r
+            for a, b in zip(ref[key], r):
+                assert np.array_equal(a["T64"], b["T64"]) and a["n_corr"] == b["n_corr"] and a["rmse"] == b["rmse"]
+    # stepping API without sharding: same result as the one-shot alignment
+    icp.set_query_order("cell")
+    icp.set_nn_reuse(True)
+    for k in range(15):
+        icp.step_begin("p2plane", first=1 if k == 0 else 0)
+        icp.step_end("p2plane", last=(k == 14))
+    stepped = icp.fetch_results()
+    for a, b in zip(ref["cell"], stepped):
+        assert np.array_equal(a["T64"], b["T64"]) and a["iterations"] == b["iterations"]
