@@ -14,8 +14,10 @@ already resident in HBM.
 N > 1: the map is tile-sharded along x (equal-count slabs + halo); `--batch` scans are in flight
 PER GPU (N x 32 in all), every rank holds the whole scan batch, accumulates only the queries
 that fall in its slab (1/N of every scan), and the 30-double normal-equation records are
-all-reduced over RCCL once per ICP iteration.  Work per GPU is fixed as N grows
-=> "scaling": "weak"; `value` = all scans of all ranks' common batch / wall time.
+all-reduced over RCCL once per ICP iteration; `--pipeline 2` steps the batch as two
+halves on two streams so that one half's all-reduce (latency-bound) overlaps the other half's
+search.  Work per GPU is fixed as N grows => "scaling": "weak"; `value` = all scans of all ranks'
+common batch / wall time.
 """
 import argparse
 import json
@@ -42,6 +44,10 @@ def parse():
     ap.add_argument("--scan-points", type=int, default=200_000)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="scans registered concurrently per step, per GPU")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="sharded runs: step the batch as this many parts on separate streams so that one part's all-reduce overlaps the "
+                         "next part's search (sharded.PipelinedShardedIcp).  With one rank 2 parts cost 17 %% (smaller kernels, twice the "
+                         "host calls); whether it pays with 8 ranks depends on the RCCL latency, to be decided on a multi-GPU measurement")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the sharded stepping path + collective even with one rank (rehearses the RCCL plumbing on one GPU)")
     ap.add_argument("--mode", default="p2plane", choices=["p2plane", "o3d_p2p"])
@@ -103,25 +109,37 @@ def main():
     B = args.batch * world                        # weak scaling: --batch scans in flight per GPU
     scans = np.stack([synth.make_scan(map_ds, args.scan_points, scan_id=rank * 0 + b)[0] for b in range(B)])
     n_scan = scans.shape[1]
-    icp = api.Icp(ctx, max_dist, args.iters, 0.05, 1e-5)
-    icp.set_target(mp)
-    icp.set_source_batch(scans)
-    icp.set_initial_batch(None)
-    icp.use_graph(not args.no_graph)
-    icp.set_query_order(args.query_order)
-    icp.set_nn_reuse(not args.no_nn_reuse)
-    xbuf = None
+    parts = max(1, min(args.pipeline, B)) if sharded_run else 1
+    while B % parts:
+        parts -= 1
+    streams = [stream] + [torch.cuda.Stream() for _ in range(parts - 1)]
+    ctxs = [ctx] + [api.Context(device, st.cuda_stream) for st in streams[1:]]
+    icps, xbufs = [], []
+    for h in range(parts):
+        part = api.Icp(ctxs[h], max_dist, args.iters, 0.05, 1e-5)
+        part.set_target(mp)                                # the map index is shared (read-only) by the parts
+        part.set_source_batch(scans[h * (B // parts):(h + 1) * (B // parts)])
+        part.set_initial_batch(None)
+        part.use_graph(not args.no_graph)
+        part.set_query_order(args.query_order)
+        part.set_nn_reuse(not args.no_nn_reuse)
+        icps.append(part)
+    icp = icps[0]
     drv = None
     if sharded_run:
         lo, hi = float(edges[rank]), float(edges[rank + 1])
-        icp.set_shard(max(lo, -1e30), min(hi, 1e30))   # finite bounds keep the sharded code path even for one rank
-        xbuf = torch.zeros(B * 32, dtype=torch.float64, device="cuda")
-        icp.set_exchange_buffer(xbuf.data_ptr(), xbuf.numel() * 8)
+        pairs = []
+        for h, part in enumerate(icps):
+            part.set_shard(max(lo, -1e30), min(hi, 1e30))   # finite bounds keep the sharded code path even for one rank
+            xb = torch.zeros((B // parts) * 32, dtype=torch.float64, device="cuda")
+            part.set_exchange_buffer(xb.data_ptr(), xb.numel() * 8)
+            xbufs.append(xb)
 
-        def allreduce():
-            with torch.cuda.stream(stream):
-                dist.all_reduce(xbuf)
-        drv = sharded.ShardedIcp(icp, args.mode, args.iters, allreduce)
+            def allreduce(xb=xb, st=streams[h]):
+                with torch.cuda.stream(st):
+                    dist.all_reduce(xb)
+            pairs.append((part, allreduce))
+        drv = sharded.PipelinedShardedIcp(pairs, args.mode, args.iters)
     setup_s = time.time() - t_setup
 
     def step():
@@ -150,7 +168,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    results = icp.fetch_results()
+    results = [r for part in icps for r in part.fetch_results()]
 
     # ---------------- correctness of what was timed: every scan must recover T_true
     terr = max(synth.pose_error(r["T64"], synth.t_true())[0] for r in results)
@@ -168,7 +186,7 @@ def main():
     icp.profile_enable(False)
     a_nn = A_NN_P2PLANE if args.mode == "p2plane" else A_NN_P2P
     nn_ms = ms_total / max(n_launch, 1)
-    queries_per_launch = n_scan * B / (world if world > 1 else 1)
+    queries_per_launch = n_scan * (B // parts) / (world if world > 1 else 1)   # the profiled part's launches
     achieved_gbs = queries_per_launch * a_nn / (nn_ms * 1e-3) / 1e9 if nn_ms > 0 else 0.0
 
     # ---------------- single-scan latency (one scan in flight, graph replay), outside the timed region
@@ -227,7 +245,7 @@ def main():
                    "parallelism": ("map sharded into %d x-slabs (+halo), every rank owns 1/%d of each scan's queries, RCCL all-reduce of the "
                                    "normal-equation records once per ICP iteration" % (world, world)) if sharded_run else "single GPU",
                    "hip_graph": (not args.no_graph) and not sharded_run,
-                   "shard_resumes": (drv.resumes if drv is not None else 0)},
+                   "shard_resumes": (drv.resumes if drv is not None else 0), "pipeline_parts": parts},
         "parity": {"max_translation_err_vs_truth_m": terr, "max_rotation_err_vs_truth_rad": rerr, "ok": bool(ok)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",

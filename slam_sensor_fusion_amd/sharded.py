@@ -65,3 +65,43 @@ class ShardedIcp:
             self.resumes += 1
             first = 2
         raise RuntimeError("sharded alignment did not finish")
+
+
+class PipelinedShardedIcp:
+    """Several parts of a batch, each an sf_icp on its own stream (with its own exchange buffer).
+
+    Per iteration the parts are stepped one after the other, so the all-reduce of one part is in
+    flight while the next part searches: the collective is latency-bound (a few KB), and this hides
+    that latency behind kernels instead of leaving the GPU idle.  Every rank issues the collectives in
+    the same order (part 0, part 1, ... per iteration).  Stale scans (see ShardedIcp) are resumed
+    for all parts together; a part without stale scans just has nothing left to do.
+    """
+
+    def __init__(self, parts, mode, num_iterations):
+        """parts: list of (icp, allreduce)."""
+        self.parts, self.mode, self.iters = parts, mode, num_iterations
+        self.resumes = 0
+
+    def n_steps(self):
+        return self.iters + 1 if self.mode == "o3d_p2p" else self.iters
+
+    def run_pass(self, first):
+        steps = self.n_steps()
+        for k in range(steps):
+            for i, (icp, allreduce) in enumerate(self.parts):
+                icp.step_begin(self.mode, first=(first[i] if k == 0 else 0))
+                allreduce()
+            for icp, _ in self.parts:
+                icp.step_end(self.mode, last=(k == steps - 1))
+
+    def align(self):
+        first = [1] * len(self.parts)
+        for _ in range(self.n_steps() + 1):
+            self.run_pass(first)
+            results = [icp.fetch_results() for icp, _ in self.parts]
+            stale = [any(r["flags"] & SF_ICP_FLAG_SHARD_STALE for r in res) for res in results]
+            if not any(stale):
+                return [r for res in results for r in res]
+            self.resumes += 1
+            first = [2 if s else 0 for s in stale]
+        raise RuntimeError("sharded alignment did not finish")

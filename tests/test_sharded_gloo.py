@@ -77,6 +77,51 @@ class NumpyShardStep:
         self.n_corr = int(rec[0])
 
 
+def worker_pipelined(rank, world, port, out_dir):
+    """Two scans as two pipelined parts (sharded.PipelinedShardedIcp): collectives interleave A, B, A, B ..."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from slam_sensor_fusion_amd import sharded, synth
+    raw = synth.make_map(60_000)
+    ds = orc.voxel_pcl(raw, 0.1)[0]
+    edges = sharded.slab_edges(ds[:, 0], world)
+    keep = sharded.slab_select(ds, edges, rank, halo=MAX_DIST + NORMAL_RADIUS + 0.25)
+    local = ds[keep]
+    normals, _ = orc.normals_radius(local, NORMAL_RADIUS)
+    parts, steps = [], []
+    for k in range(2):
+        scan = synth.make_scan(ds, 2000, scan_id=10 + k)[0]
+        xchg = torch.zeros(32, dtype=torch.float64)
+        st = NumpyShardStep(orc, local, normals, scan, edges[rank], edges[rank + 1], xchg)
+        steps.append(st)
+        parts.append((st, (lambda x=xchg: dist.all_reduce(x))))
+    drv = sharded.PipelinedShardedIcp(parts, "p2plane", ITERS)
+    res = drv.align()
+    assert len(res) == 2 and all(r["iterations"] == ITERS for r in res) and drv.resumes == 0
+    for k, st in enumerate(steps):
+        np.save(os.path.join(out_dir, "P%d_T_%d.npy" % (k, rank)), st.T)
+    dist.destroy_process_group()
+
+
+def test_two_rank_pipelined_parts_equal_unsharded(orc, synth, tmp_path):
+    world = 2
+    mp.spawn(worker_pipelined, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    raw = synth.make_map(60_000)
+    ds = orc.voxel_pcl(raw, 0.1)[0]
+    normals, _ = orc.normals_radius(ds, NORMAL_RADIUS)
+    for k in range(2):
+        T0, T1 = np.load(tmp_path / ("P%d_T_0.npy" % k)), np.load(tmp_path / ("P%d_T_1.npy" % k))
+        assert np.array_equal(T0, T1)
+        scan = synth.make_scan(ds, 2000, scan_id=10 + k)[0]
+        ref = orc.icp_p2plane(scan, ds, normals, None, MAX_DIST, ITERS)
+        dt, dr = synth.pose_error(T0, ref["T"])
+        assert dt < 1e-9 and dr < 1e-9
+
+
 def worker(rank, world, port, out_dir):
     import sys
     sys.path.insert(0, ROOT)
