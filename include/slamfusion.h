@@ -85,6 +85,9 @@ int sf_cloud_crop_obb(sf_cloud *c, const double center[3], const double R[9], co
 /* a8: applyTransformation — icp_point_to_point.cpp:99-110 (general affine 3x4, float32,
  * unfused multiply/add so results are bit-identical to the reference's x86-64 build) */
 int sf_cloud_transform(sf_cloud *c, const float T[16]);
+/* `*map_cloud += *cloud` — global_map_frames_manager.cpp:131: dst <- [dst; src] on the device (src unchanged).
+ * Map growth = transform the registered scan into the map frame, append, voxel-downsample, sf_map_build. */
+int sf_cloud_append(sf_cloud *dst, const sf_cloud *src);
 /* indices (into the cloud before the call) kept by the LAST crop/subsample on this cloud */
 int sf_cloud_last_indices(sf_cloud *c, int32_t *idx, int64_t cap, int64_t *n);
 

@@ -215,6 +215,10 @@ class Cloud:
         _check(self.lib.sf_cloud_crop_obb(self.h, _p(c), _p(R), _p(e)))
         return self
 
+    def append(self, other):                         # *map_cloud += *cloud
+        _check(self.lib.sf_cloud_append(self.h, other.h))
+        return self
+
     def transform(self, T):                          # applyTransformation
         T = _f32(T).reshape(16)
         _check(self.lib.sf_cloud_transform(self.h, _p(T)))

@@ -529,6 +529,33 @@ extern "C" int sf_cloud_transform(sf_cloud *c, const float T[16])
     return SF_OK;
 }
 
+// *map_cloud += *cloud (global_map_frames_manager.cpp:131): dst <- [dst; src], on the device.  Together with
+// sf_cloud_transform, sf_cloud_voxel_downsample and sf_map_build this is incremental map growth.
+extern "C" int sf_cloud_append(sf_cloud *dst, const sf_cloud *src)
+{
+    SF_CHECK(dst && src && dst != src, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(dst->ctx->device == src->ctx->device, SF_ERR_INVALID, "clouds live on different devices");
+    SF_CHECK(dst->n + src->n < (int64_t)0x7fffffff, SF_ERR_OVERFLOW, "cloud too large for 32-bit point ids");
+    SF_HIP(hipSetDevice(dst->ctx->device));
+    if (src->n == 0) return SF_OK;
+    hipStream_t s = dst->ctx->stream;
+    if (src->ctx->stream != s) SF_HIP(hipStreamSynchronize(src->ctx->stream)); // src must be complete before dst's stream reads it
+    const size_t b0 = sizeof(float) * 3 * (size_t)dst->n, b1 = sizeof(float) * 3 * (size_t)src->n;
+    if (b0 + b1 > dst->xyz.cap) { // DevBuf::reserve does not keep the content: grow by hand (1.5 x so repeated appends stay linear)
+        sf::DevBuf nb;
+        SF_TRY(nb.reserve(b0 + b1 + ((b0 + b1) >> 1)));
+        if (b0) SF_HIP(hipMemcpyAsync(nb.p, dst->xyz.p, b0, hipMemcpyDeviceToDevice, s));
+        SF_HIP(hipStreamSynchronize(s));
+        dst->xyz.release();
+        dst->xyz = nb;
+    }
+    SF_HIP(hipMemcpyAsync(static_cast<char *>(dst->xyz.p) + b0, src->xyz.p, b1, hipMemcpyDeviceToDevice, s));
+    dst->n += src->n;
+    dst->n_last_idx = -1;
+    dst->n_vox_point_vals = dst->n_vox_out_vals = dst->n_vox_out_pts = 0;
+    return SF_OK;
+}
+
 // ------------------------------------------------------------------ bounds of the finite points
 namespace {
 struct MinMaxDev { float mn[3], mx[3]; unsigned long long cnt; };

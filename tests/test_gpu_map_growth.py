@@ -1,0 +1,77 @@
+"""Incremental map growth (BASELINE config 4; the reference merges clouds with `*map_cloud += *cloud`,
+global_map_frames_manager.cpp:131, and voxel-filters the sum, :142-146): a registered scan is
+transformed into the map frame, appended to the map cloud on the device, the voxel grid is applied
+again and the index rebuilt.  Bit-exact against the oracle's voxel grid of the same concatenation."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_map_grows_by_registered_scans(api, ctx, orc, synth):
+    rng = np.random.default_rng(11)
+    world = synth.make_map(400_000)                                  # 20 m x 20 m x 10 m
+    west = world[world[:, 0] < 2.0]                                  # the map knows the western part only
+    map_cloud = api.Cloud(ctx, west)
+    assert map_cloud.voxel_downsample(0.1, "pcl") == 0
+    ds0 = map_cloud.download()
+    ref0 = orc.voxel_pcl(west, 0.1)[0]
+    assert np.array_equal(ds0, ref0)
+
+    # a scan that sees x in [-2, 6]: half known, half new, taken from pose T
+    T = synth.make_T((0.05, -0.03, 0.02), (0.1, -0.2, 0.5))
+    seen = world[(world[:, 0] > -2.0) & (world[:, 0] < 6.0)]
+    seen = seen[rng.choice(len(seen), 60_000, replace=False)]
+    Ti = np.linalg.inv(T)
+    scan = (seen.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+
+    # register it against the old map (only the overlapping part finds neighbours)
+    mp = api.Map(ctx, map_cloud, 0.25)
+    icp = api.Icp(ctx, 0.5, 30, 0.05, 1e-5)
+    icp.set_target(mp)
+    icp.set_source(scan)
+    r = icp.align("o3d_p2p")
+    dt, dr = synth.pose_error(r["T64"], T)
+    assert 0.3 < r["fitness"] < 0.8 and dt < 0.05 and dr < 5e-3           # the unknown half pulls on the boundary points
+
+    # grow: transform by the estimated pose, append, voxel grid, rebuild
+    reg = api.Cloud(ctx, scan).transform(r["T"])
+    reg_host = reg.download()
+    Tf = np.asarray(r["T"], dtype=np.float32)
+    x, y, z = scan[:, 0], scan[:, 1], scan[:, 2]
+    assert np.array_equal(reg_host, np.stack([Tf[k, 0] * x + Tf[k, 1] * y + Tf[k, 2] * z + Tf[k, 3] for k in range(3)], 1))   # icp_point_to_point.cpp:103-105
+    n_before = len(map_cloud)
+    map_cloud.append(reg)
+    assert len(map_cloud) == n_before + len(scan) and len(reg) == len(scan)
+    assert np.array_equal(map_cloud.download(), np.concatenate([ds0, reg_host]))
+    assert map_cloud.voxel_downsample(0.1, "pcl") == 0
+    grown = map_cloud.download()
+    assert np.array_equal(grown, orc.voxel_pcl(np.concatenate([ds0, reg_host]), 0.1)[0])
+    assert grown[:, 0].max() > 5.5 and len(grown) > len(ds0)
+
+    # a second scan, further east, now locks on the grown map with nearly all of its points
+    mp2 = api.Map(ctx, map_cloud, 0.25)
+    seen2 = world[(world[:, 0] > 1.0) & (world[:, 0] < 5.5)]
+    seen2 = seen2[rng.choice(len(seen2), 40_000, replace=False)]
+    T2 = synth.make_T((-0.04, 0.06, 0.01), (0.0, 0.1, -0.4))
+    T2i = np.linalg.inv(T2)
+    scan2 = (seen2.astype(np.float64) @ T2i[:3, :3].T + T2i[:3, 3]).astype(np.float32)
+    icp.set_target(mp2)
+    icp.set_source(scan2)
+    r2 = icp.align("o3d_p2p")
+    icp.set_target(mp)
+    r_old = icp.align("o3d_p2p")
+    assert r2["fitness"] > 0.9 and r2["fitness"] > r_old["fitness"] + 0.3
+    dt, dr = synth.pose_error(r2["T64"], T2)
+    assert dt < 0.05 and dr < 5e-3
+    # appending an empty cloud and appending across buffers that must grow several times
+    empty = api.Cloud(ctx, np.zeros((0, 3), np.float32))
+    n = len(map_cloud)
+    map_cloud.append(empty)
+    assert len(map_cloud) == n
+    acc = api.Cloud(ctx, west[:10])
+    for k in range(1, 6):
+        acc.append(api.Cloud(ctx, west[10 * k:10 * (k + 1) * (k + 1)]))
+    assert np.array_equal(acc.download(), np.concatenate([west[:10]] + [west[10 * k:10 * (k + 1) * (k + 1)] for k in range(1, 6)]))
+    with pytest.raises(api.SlamFusionError):
+        acc.append(acc)
