@@ -1,15 +1,18 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of a round on the GPU box and write the summaries under profiles/:
-#   tools/profile_round.sh r01        (run through gpurun; raw output stays in /tmp on the box)
+#   tools/profile_round.sh r01              (run through gpurun; raw output stays in /tmp on the box)
+#   tools/profile_round.sh r01_search --no-nn-reuse   (extra bench.py arguments: here every query searches in every launch)
 # Timing pass: --kernel-trace --stats.  Counter passes: --pmc only, one group per run (gpurun refuses
 # --pmc together with tracing flags).  Command profiled: the default bench workload, 3 steps.
 set -e
 P=${1:-r01}
+shift || true
+EXTRA="$*"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT="$GRAFT_REPO_ROOT/gpurun_out/profiles_$P"
 W=/tmp/prof_$P
 mkdir -p "$OUT" "$W"
-CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph"
+CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph $EXTRA"
 run() { # name, rocprofv3 args...
     local name=$1; shift
     timeout -k 10 200 rocprofv3 "$@" -d "$W/$name" -o t --output-format csv -- $CMD > "$OUT/$name.log" 2>&1
@@ -28,8 +31,12 @@ run sq2 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
 run ta --pmc TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
 run td --pmc TD_TD_BUSY_sum TD_TC_STALL_sum
 run tcp --pmc TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum
+if [ -z "$EXTRA" ]; then
 python3 bench.py 2>/dev/null | tail -1 > "$OUT/${P}_bench_default.json"
 for B in 1 2 4 8 16 64; do python3 bench.py --batch $B --steps 10 --no-cpu-baseline 2>/dev/null | tail -1; done > "$OUT/${P}_bench_sweep.jsonl"
 python3 bench.py --force-dist --steps 10 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${P}_bench_forcedist.json"
+else
+python3 bench.py --no-cpu-baseline $EXTRA 2>/dev/null | tail -1 > "$OUT/${P}_bench.json"
+fi
 rm -f "$OUT"/*.log
 ls "$OUT"
