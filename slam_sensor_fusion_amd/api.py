@@ -697,6 +697,63 @@ def mat4f_mul(A, B):
     return out.reshape(4, 4)
 
 
+class Ekf:
+    """sf_ekf: error-state EKF pose prior with IMU pre-integration (extension f-4; the reference has none)."""
+
+    def __init__(self):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        _check(self.lib.sf_ekf_create(C.byref(self.h)))
+
+    def reset(self, T, v=None, P_diag=None):
+        T = _f64(T).reshape(16)
+        v = None if v is None else _f64(v).reshape(3)
+        P = None if P_diag is None else _f64(P_diag).reshape(9)
+        _check(self.lib.sf_ekf_reset(self.h, _p(T), _p(v) if v is not None else None, _p(P) if P is not None else None))
+
+    def set_noise(self, gyro_sigma, accel_sigma, gravity=None):
+        g = None if gravity is None else _f64(gravity).reshape(3)
+        _check(self.lib.sf_ekf_set_noise(self.h, C.c_double(gyro_sigma), C.c_double(accel_sigma), _p(g) if g is not None else None))
+
+    def predict_imu(self, gyro, accel, dt):
+        gyro, accel = _f64(gyro).reshape(-1, 3), _f64(accel).reshape(-1, 3)
+        assert len(gyro) == len(accel)
+        _check(self.lib.sf_ekf_predict_imu(self.h, _p(gyro), _p(accel), C.c_int64(len(gyro)), C.c_double(dt)))
+
+    def predict_odometry(self, T_prev, T_cur, cov_pos=None, cov_rot=None):
+        a, b = _f64(T_prev).reshape(16), _f64(T_cur).reshape(16)
+        cp = None if cov_pos is None else _f64(cov_pos).reshape(3)
+        cr = None if cov_rot is None else _f64(cov_rot).reshape(3)
+        _check(self.lib.sf_ekf_predict_odometry(self.h, _p(a), _p(b), _p(cp) if cp is not None else None, _p(cr) if cr is not None else None))
+
+    def update_position(self, z, cov):
+        z, cov = _f64(z).reshape(3), _f64(cov).reshape(9)
+        _check(self.lib.sf_ekf_update_position(self.h, _p(z), _p(cov)))
+
+    def update_yaw(self, yaw, var):
+        _check(self.lib.sf_ekf_update_yaw(self.h, C.c_double(yaw), C.c_double(var)))
+
+    def update_pose(self, T, cov_pos, cov_rot):
+        T, cp, cr = _f64(T).reshape(16), _f64(cov_pos).reshape(3), _f64(cov_rot).reshape(3)
+        _check(self.lib.sf_ekf_update_pose(self.h, _p(T), _p(cp), _p(cr)))
+
+    def state(self):
+        T, v, P = np.empty(16), np.empty(3), np.empty(81)
+        _check(self.lib.sf_ekf_get(self.h, _p(T), _p(v), _p(P)))
+        return T.reshape(4, 4), v, P.reshape(9, 9)
+
+    def close(self):
+        if self.h:
+            self.lib.sf_ekf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class StochasticFilter:
     """sf_sfilter: StochasticFilter of localization/src/stochastic_filter.cpp."""
 
