@@ -129,17 +129,66 @@ class LocalizationFlow:
                 return None
 
         # FINE ALIGNMENT :318-338
+        prior = self.pose_prior(gps, odom, odom_T_sensor_current)
+        self.icp_.set_source(scan)
+        self.icp_.set_initial_transformation(prior.astype(np.float32))
+        result = self.icp_.align("ref_cpp")
+        self.map_T_sensor_ = result["T"]                     # no has_converged check, :338
+        self.after_alignment(result)
+        self.odom_T_sensor_previous_ = odom_T_sensor_current  # :341
+        self.last.update(prior=prior, icp=result, n_scan=len(scan))
+        return self.map_T_sensor_
+
+    def pose_prior(self, gps, odom, odom_T_sensor_current):
+        """The reference's prior (:318-332): odometry prediction, GPS/compass pose, covariance-weighted blend, StochasticFilter."""
         map_T_sensor_odom = api.odom_prediction(self.map_T_sensor_, self.odom_T_sensor_previous_, odom_T_sensor_current)
         map_T_sensor_gps = self.computeGpsCoarsePoseInMapFrame(gps["latitude"], gps["longitude"])
         odometry_gain, gps_compass_gain = api.pose_gains(gps["position_covariance"], odom["covariance"], fixed=False)
         prior = api.blend(odometry_gain, map_T_sensor_odom, gps_compass_gain, map_T_sensor_gps)
         self.coarse_pose_filter_.addPoseToQueue(prior)
         prior = self.coarse_pose_filter_.applyGaussianFilterToCurrentPose(self.map_T_sensor_, prior)
-        self.icp_.set_source(scan)
-        self.icp_.set_initial_transformation(prior.astype(np.float32))
-        result = self.icp_.align("ref_cpp")
-        self.map_T_sensor_ = result["T"]                     # no has_converged check, :338
-        self.odom_T_sensor_previous_ = odom_T_sensor_current  # :341
-        self.last = dict(prior=prior, odom=map_T_sensor_odom, gps=map_T_sensor_gps, icp=result,
-                         gains=(odometry_gain, gps_compass_gain), n_scan=len(scan))
-        return self.map_T_sensor_
+        self.last = dict(odom=map_T_sensor_odom, gps=map_T_sensor_gps, gains=(odometry_gain, gps_compass_gain))
+        return prior
+
+    def after_alignment(self, result):
+        pass
+
+
+class EkfLocalizationFlow(LocalizationFlow):
+    """The same per-scan orchestration with the pose prior from the error-state EKF (extension f-4, sf_ekf_*)
+    instead of blend + StochasticFilter: odometry-delta prediction, GPS position and compass yaw updates before
+    the alignment, the ICP pose as a measurement after it.  Not reference behaviour."""
+
+    icp_pos_var_ = 0.05 ** 2            # the alignment stops at a 5 cm mean error (acceptable_mean_error)
+    icp_rot_var_ = np.radians(0.5) ** 2
+    compass_var_ = np.radians(2.0) ** 2
+    start_sigma_m_ = 0.05
+    start_sigma_rad_ = np.radians(0.5)
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.ekf_ = api.Ekf()
+        self.ekf_started_ = False
+
+    def pose_prior(self, gps, odom, odom_T_sensor_current):
+        if not self.ekf_started_:
+            # the start pose is a lock (coarse alignment or the caller's), not a GPS fix: a GPS-sized initial
+            # covariance would let the first 0.5 m GPS sample drag the prior out of the ICP's reach
+            self.ekf_.reset(self.map_T_sensor_.astype(np.float64), None, [self.start_sigma_m_ ** 2] * 3 + [1.0] * 3 + [self.start_sigma_rad_ ** 2] * 3)
+            self.ekf_started_ = True
+        cov = np.asarray(odom["covariance"], dtype=np.float64).reshape(6, 6)
+        self.ekf_.predict_odometry(self.odom_T_sensor_previous_.astype(np.float64), odom_T_sensor_current.astype(np.float64),
+                                   np.diag(cov)[:3], np.diag(cov)[3:])
+        if "map_xyz" in gps:                                 # GPS already expressed in the map frame
+            p_gps = np.asarray(gps["map_xyz"], dtype=np.float64)
+        else:
+            p_gps = self.computeGpsCoarsePoseInMapFrame(gps["latitude"], gps["longitude"])[:3, 3].astype(np.float64)
+        self.ekf_.update_position(p_gps, np.asarray(gps["position_covariance"], dtype=np.float64).reshape(3, 3))
+        self.ekf_.update_yaw(float(self.current_compass_yaw_), self.compass_var_)
+        prior = self.ekf_.state()[0]
+        self.last = dict(gps=p_gps)
+        return prior.astype(np.float32)
+
+    def after_alignment(self, result):
+        self.ekf_.update_pose(np.asarray(result["T"], dtype=np.float64), [self.icp_pos_var_] * 3, [self.icp_rot_var_] * 3)
+        self.map_T_sensor_ = self.ekf_.state()[0].astype(np.float32)
