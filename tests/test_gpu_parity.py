@@ -493,8 +493,9 @@ def test_nn_reuse_fuzz(api, ctx, synth):
     """Randomised scenes for the neighbour-reuse certificate: clustered and duplicated map points,
     points on cell faces, sparse maps, several cell sizes, large and tiny start offsets — the
     registration must not depend on the switch in a single bit."""
-    rng = np.random.default_rng(77)
-    for trial in range(24):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("SF_FUZZ_SEED", "77")))
+    for trial in range(int(os.environ.get("SF_FUZZ_TRIALS", "24"))):
         kind = trial % 4
         n_map = int(rng.integers(2_000, 60_000))
         if kind == 0:                                   # uniform volume
@@ -502,7 +503,8 @@ def test_nn_reuse_fuzz(api, ctx, synth):
         elif kind == 1:                                 # clusters + exact duplicates
             c = rng.uniform(-6, 6, (40, 3))
             m = c[rng.integers(0, 40, n_map)] + rng.normal(0, 0.15, (n_map, 3))
-            m[::7] = m[1::7][: len(m[::7])]
+            k7 = len(m[1::7])
+            m[::7][:k7] = m[1::7]
         elif kind == 2:                                 # points snapped to a lattice: ties and cell faces
             m = np.round(rng.uniform(-6, 6, (n_map, 3)) * 8) / 8
         else:                                           # planes
