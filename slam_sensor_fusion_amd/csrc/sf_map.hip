@@ -70,9 +70,13 @@ template <bool WINDOW>
 __global__ __launch_bounds__(256) void k_map_nn_t(SfGrid g, SfWindow w, const float *__restrict__ q, int64_t n, float thr, int32_t *__restrict__ idx,
                                                  float *__restrict__ d2)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    sf::NNHit hit = sf::nn_search<WINDOW>(g, w, q[3 * i], q[3 * i + 1], q[3 * i + 2], thr);
+    // the wave-cooperative search of the ICP kernel (every lane of the wave takes part, with or without a query)
+    __shared__ sf::WaveNN ws[256 / 64];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    const float qx = valid ? q[3 * i] : 0.0f, qy = valid ? q[3 * i + 1] : 0.0f, qz = valid ? q[3 * i + 2] : 0.0f;
+    const sf::NNHit hit = sf::nn_search_wave<WINDOW>(g, w, valid, qx, qy, qz, thr, &ws[threadIdx.x >> 6]);
+    if (!valid) return;
     idx[i] = hit.j >= 0 ? (int32_t)__float_as_uint(g.pts[hit.j].w) : -1;
     d2[i] = hit.j >= 0 ? hit.d2 : INFINITY;
 }

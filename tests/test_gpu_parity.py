@@ -574,3 +574,35 @@ def test_switches_between_alignments_with_graph_replay(api, ctx, synth, small_wo
     stepped = icp.fetch_results()
     for a, b in zip(ref["cell"], stepped):
         assert np.array_equal(a["T64"], b["T64"]) and a["iterations"] == b["iterations"]
+
+
+def test_nn_exact_fuzz(api, ctx, orc):
+    """sf_map_nn (the ICP kernel's wave-cooperative search) against the oracle's exact kd-tree on
+    uniform, clustered, lattice and planar maps, several cell sizes, thresholds and query noises, with
+    coordinates up to 3 km from the origin (stresses the float32 slack of the pruning bounds): the hit
+    set and every squared distance must be bit-identical."""
+    rng = np.random.default_rng(2024)
+    for trial in range(16):
+        kind = trial % 4
+        n = int(rng.integers(5_000, 120_000))
+        if kind == 0:
+            m = rng.uniform(-20, 20, (n, 3))
+        elif kind == 1:
+            c = rng.uniform(-20, 20, (60, 3))
+            m = c[rng.integers(0, 60, n)] + rng.normal(0, 0.3, (n, 3))
+        elif kind == 2:
+            m = np.round(rng.uniform(-20, 20, (n, 3)) * 8) / 8
+        else:
+            m = rng.uniform(-20, 20, (n, 3))
+            m[: n // 2, 2] = 0.0
+        m = m.astype(np.float32) + np.float32(rng.choice([0.0, 500.0, 3000.0]))
+        mp = api.Map(ctx, api.Cloud(ctx, m), float(rng.choice([0.0, 0.1, 0.25, 0.5, 1.0])))
+        q = (m[rng.integers(0, n, 10_000)] + rng.normal(0, rng.choice([0.001, 0.05, 0.5]), (10_000, 3))).astype(np.float32)
+        thr = float(rng.choice([0.25, 1.0, 1e9]))
+        gi, gd = mp.nn(q, thr)
+        oi, od = orc.KdTreeF(m).nn(q)
+        ok = od < thr
+        assert np.array_equal(gi >= 0, ok), trial
+        assert np.array_equal(gd[ok], od[ok]), trial
+        uniq = ok & (m[np.maximum(gi, 0)] == m[np.maximum(oi, 0)]).all(1)
+        assert uniq.sum() == ok.sum(), trial                 # same point up to exact duplicates
