@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 100
+#define SF_VERSION 200
 
 typedef enum {
     SF_OK = 0,
@@ -95,6 +95,14 @@ int sf_cloud_last_indices(sf_cloud *c, int32_t *idx, int64_t cap, int64_t *n);
  * pc2.read_points, localization_node.py:106-111): raw little-endian message buffer,
  * n_points = width*height, float32 fields at byte offsets off_x/y/z inside point_step */
 int sf_cloud_from_pointcloud2(sf_cloud *c, const void *data, int64_t n_points, int point_step, int off_x, int off_y, int off_z);
+/* the whole sensor_msgs/PointCloud2 contract, checked: data_bytes must cover height rows of row_step bytes
+ * (row_step = 0: width * point_step), x/y/z datatype 7 (FLOAT32) or 8 (FLOAT64, rounded to float32 like
+ * pcl::fromROSMsg's field mapping), big-endian payloads are refused (SF_ERR_INVALID).  No allocation and no host
+ * synchronisation per call once the staging buffer has grown to the message size. */
+#define SF_PC2_FLOAT32 7
+#define SF_PC2_FLOAT64 8
+int sf_cloud_from_pointcloud2_msg(sf_cloud *c, const void *data, int64_t data_bytes, int64_t width, int64_t height, int point_step, int64_t row_step,
+                                  int off_x, int off_y, int off_z, int datatype, int is_bigendian);
 /* f-3: PCD v0.7 files (ascii / binary / binary_compressed read; "DATA binary" write exactly
  * as pcl::io::savePCDFileBinary does for PointXYZ — mapping/src/map_data_save_node.cpp:74) */
 int sf_cloud_load_pcd(sf_cloud *c, const char *path);
@@ -111,6 +119,10 @@ void sf_free(void *p);
  * ordered by (i,j,k). */
 #define SF_VOXEL_PCL 0
 #define SF_VOXEL_O3D 1
+/* EXTENSION (no reference counterpart): pcl::VoxelGrid's arithmetic with the linear index kept in 64 bits, for maps
+ * past 2^31 voxels (BASELINE config 5: a 50 M-point city at leaf 0.1 m) where PCL -- and SF_VOXEL_PCL -- return the
+ * cloud unfiltered.  Wherever SF_VOXEL_PCL does not overflow the two give identical ids, order and centroids. */
+#define SF_VOXEL_PCL64 2
 #define SF_FLAG_VOXEL_OVERFLOW 1
 int sf_cloud_voxel_downsample(sf_cloud *c, double leaf, int flavour, int *status_flags);
 /* introspection for parity tests: per-input-point voxel ids of the LAST downsample
@@ -119,6 +131,8 @@ int sf_cloud_voxel_downsample(sf_cloud *c, double leaf, int flavour, int *status
 int sf_cloud_voxel_point_ids(sf_cloud *c, int32_t *ids, int64_t cap_values, int64_t *n_values);
 int sf_cloud_voxel_out_ids(sf_cloud *c, int32_t *ids, int64_t cap_values, int64_t *n_values);
 int sf_cloud_voxel_out_means_f64(sf_cloud *c, double *xyz, int64_t cap_points, int64_t *n_points);
+int sf_cloud_voxel_point_ids64(sf_cloud *c, int64_t *ids, int64_t cap_values, int64_t *n_values); /* after SF_VOXEL_PCL64 */
+int sf_cloud_voxel_out_ids64(sf_cloud *c, int64_t *ids, int64_t cap_values, int64_t *n_values);
 
 /* ------------------------------------------------------------------ map (NN index) */
 /* a6: setTargetPointCloud — icp_point_to_point.cpp:49-55.  Instead of a FLANN kd-tree
@@ -140,6 +154,11 @@ int sf_map_window_obb(sf_map *m, const double center[3], const double R[9], cons
 int sf_map_window_count(sf_map *m, int64_t *n);
 /* extension x2 (no reference code): PCA normals from neighbours within `radius` */
 int sf_map_estimate_normals(sf_map *m, float radius);
+/* the same pass also keeps each point's 3x3 neighbourhood covariance (6 unique float64 entries xx xy xz yy yz zz,
+ * centred on the neighbourhood mean, divided by the neighbour count; zeros below 3 neighbours) -- SURVEY x2
+ * "normals + covariance", BASELINE config 5 */
+int sf_map_estimate_normals_cov(sf_map *m, float radius, int with_covariance);
+int sf_map_download_covariances(sf_map *m, double *cov6, int64_t cap_points, int64_t *n); /* original point order */
 int sf_map_set_normals(sf_map *m, const float *normals, int64_t n); /* original point order */
 int sf_map_download_normals(sf_map *m, float *normals, int32_t *n_neighbors, int64_t cap, int64_t *n);
 /* raw exact 1-NN (a9 without the threshold): idx in ORIGINAL point order, d2 squared
@@ -284,6 +303,19 @@ int sf_frames_get_map_cloud(sf_frames *fr, sf_cloud *out, float voxel_size, int 
 int sf_frames_get_map_T_global(sf_frames *fr, double T[16]);
 float sf_frames_get_closest_altitude(sf_frames *fr, double lat, double lon);
 int sf_frames_altitude_table(sf_frames *fr, double *table_lat_lon_alt, int64_t cap_rows, int64_t *rows);
+
+/* ------------------------------------------------------------------ MapDataSaver file writers (recorder side of f-3) */
+/* mapping/src/map_data_save_node.cpp:12-29 (folder wiped and re-created, "tx ty tz" / "lat lon alt y" headers),
+ * :61-98 (per synchronized cloud/GPS/odometry triple: cloud appended to the open tile, cloud_<counter>.pcd written
+ * with savePCDFileBinary every 10 clouds -- map_data_save_node.h:72 --, one line per log: odometry with default
+ * ostream formatting, GPS with std::fixed << std::setprecision(8)), :100-112 (open tile flushed on shutdown).
+ * compass_yaw is the recorder's own double conversion of the heading (:38-49): sf_recorder_compass_yaw. */
+typedef struct sf_recorder sf_recorder;
+int sf_recorder_create(const char *map_data_path, sf_recorder **out);
+int sf_recorder_add(sf_recorder *r, const float *xyz, int64_t n, const double odom_xyz[3], double lat, double lon, double alt, double compass_yaw);
+int sf_recorder_shutdown(sf_recorder *r);
+void sf_recorder_destroy(sf_recorder *r);
+double sf_recorder_compass_yaw(double compass_hdg_deg);
 
 /* ------------------------------------------------------------------ pose fusion (host, float32 like the reference) */
 /* a14: computePosePredictionFromOdometry — localization_node.cpp:89-110 */

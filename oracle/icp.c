@@ -292,7 +292,7 @@ static int cp_cmp(const void *a, const void *b)
     return (x->pt > y->pt) - (x->pt < y->pt);
 }
 
-void orc_normals_radius(const float *xyz, int n, double radius, float *normals, int *n_neighbors)
+static void normals_impl(const float *xyz, int n, double radius, float *normals, int *n_neighbors, double *cov6)
 {
     if (n <= 0) return;
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -354,11 +354,25 @@ void orc_normals_radius(const float *xyz, int n, double radius, float *normals, 
                 double M[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]}, nv[3];
                 smallest_eigvec(M, nv);
                 normals[3 * (size_t)i] = (float)nv[0]; normals[3 * (size_t)i + 1] = (float)nv[1]; normals[3 * (size_t)i + 2] = (float)nv[2];
+                if (cov6) for (int d = 0; d < 6; ++d) cov6[6 * (size_t)i + d] = C[d] / cnt; /* xx xy xz yy yz zz, normalised by the neighbour count */
             }
         }
-        if (cnt < 3) { normals[3 * (size_t)i] = 0; normals[3 * (size_t)i + 1] = 0; normals[3 * (size_t)i + 2] = 1; }
+        if (cnt < 3) {
+            normals[3 * (size_t)i] = 0; normals[3 * (size_t)i + 1] = 0; normals[3 * (size_t)i + 2] = 1;
+            if (cov6) for (int d = 0; d < 6; ++d) cov6[6 * (size_t)i + d] = 0.0;
+        }
         if (n_neighbors) n_neighbors[i] = cnt;
     }
     free(cp);
     free(start);
+}
+
+void orc_normals_radius(const float *xyz, int n, double radius, float *normals, int *n_neighbors)
+{
+    normals_impl(xyz, n, radius, normals, n_neighbors, NULL);
+}
+
+void orc_normals_radius_cov(const float *xyz, int n, double radius, float *normals, int *n_neighbors, double *cov6)
+{
+    normals_impl(xyz, n, radius, normals, n_neighbors, cov6);
 }

@@ -176,6 +176,16 @@ def voxel_pcl(xyz, leaf=0.1):
     return out[:k].copy(), vidx, ovox[:k].copy(), 0
 
 
+def voxel_pcl64(xyz, leaf=0.1):
+    """int64-index variant of voxel_pcl (never overflows) -> (centroids, per-point index int64, per-voxel index int64)"""
+    xyz = _f32(xyz).reshape(-1, 3)
+    out = np.empty_like(xyz)
+    vidx = np.empty(len(xyz), np.int64)
+    ovox = np.empty(len(xyz), np.int64)
+    k = lib().orc_voxel_pcl64(_p(xyz), C.c_int(len(xyz)), C.c_float(leaf), _p(out), _p(vidx), _p(ovox))
+    return out[:k].copy(), vidx, ovox[:k].copy()
+
+
 def voxel_o3d(xyz, voxel=0.1):
     """-> (means f64 [k,3], per-point ijk int32 [n,3], per-voxel ijk [k,3], status)"""
     xyz = _f64(xyz).reshape(-1, 3)
@@ -242,6 +252,15 @@ def normals_radius(xyz, radius):
     cnt = np.empty(len(xyz), np.int32)
     lib().orc_normals_radius(_p(xyz), C.c_int(len(xyz)), C.c_double(radius), _p(nrm), _p(cnt))
     return nrm, cnt
+
+
+def normals_radius_cov(xyz, radius):
+    xyz = _f32(xyz).reshape(-1, 3)
+    nrm = np.empty_like(xyz)
+    cnt = np.empty(len(xyz), np.int32)
+    cov = np.empty((len(xyz), 6), np.float64)
+    lib().orc_normals_radius_cov(_p(xyz), C.c_int(len(xyz)), C.c_double(radius), _p(nrm), _p(cnt), _p(cov))
+    return nrm, cnt, cov
 
 
 # ---------------------------------------------------------------- fusion

@@ -78,6 +78,9 @@ int orc_crop_obb(const float *xyz, int n, const double center[3], const double R
  * ascending.  Centroids: f32 sums in ascending point index order within the voxel. */
 int orc_voxel_pcl(const float *xyz, int n, float leaf, float *out, int32_t *vox_idx,
                   int32_t *out_vox);
+/* The same arithmetic with an int64 linear index: never reports overflow (extension for maps past
+ * 2^31 voxels; equals orc_voxel_pcl wherever that does not overflow). */
+int orc_voxel_pcl64(const float *xyz, int n, float leaf, float *out, int64_t *vox_idx, int64_t *out_vox);
 /* Open3D voxel_down_sample (float64) — localization_node.py:47.  ijk (optional, n*3)
  * receives int32 voxel coordinates; output sorted by (i,j,k) lexicographic (Open3D's own
  * order is unordered_map order — compare as a set); out_ijk optional (count*3). */
@@ -126,6 +129,10 @@ int orc_icp_p2plane(const float *src, int n, const float *tgt, const float *tgt_
  * (self included); < 3 neighbours => (0,0,1).  Sign: n.z >= 0 (then n.y, n.x). */
 void orc_normals_radius(const float *xyz, int n, double radius, float *normals,
                         int *n_neighbors);
+/* the same plus each point's neighbourhood covariance (xx xy xz yy yz zz, centred, divided by the
+ * neighbour count; zeros below 3 neighbours) -- SURVEY x2 "+6 cov", BASELINE config 5 */
+void orc_normals_radius_cov(const float *xyz, int n, double radius, float *normals,
+                            int *n_neighbors, double *cov6);
 
 /* ------------------------------------------------------------------ pose fusion (host) */
 /* UTM::LLtoUTM — geo_lib.hpp:38-83 (always +10 000 000 N). */

@@ -153,3 +153,80 @@ int orc_voxel_o3d(const double *xyz, int n, double voxel, double *out, int32_t *
     free(v);
     return nout;
 }
+
+/* orc_voxel_pcl64 — the SAME arithmetic as orc_voxel_pcl (float32 inverse leaf, floorf, min_b
+ * offsets, float32 centroid sums in ascending point index) with the linear voxel index kept in
+ * int64, so the "Leaf size is too small ... Integer indices would overflow" early return of
+ * pcl::VoxelGrid never triggers.  No reference counterpart (the reference's PCL returns its input
+ * unchanged there, global_map_frames_manager.cpp:142-146): a documented extension for maps past
+ * 2^31 voxels (BASELINE config 5); on inputs that do not overflow it equals orc_voxel_pcl. */
+typedef struct { int64_t vox; int pt; } vp64_t;
+static int vp64_cmp(const void *a, const void *b)
+{
+    const vp64_t *x = (const vp64_t *)a, *y = (const vp64_t *)b;
+    if (x->vox != y->vox) return x->vox < y->vox ? -1 : 1;
+    return (x->pt > y->pt) - (x->pt < y->pt);
+}
+
+int orc_voxel_pcl64(const float *xyz, int n, float leaf, float *out, int64_t *vox_idx, int64_t *out_vox)
+{
+    if (n <= 0) return 0;
+    const float inv = 1.0f / leaf;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int finite_cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        const float *p = xyz + 3 * (size_t)i;
+        if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) continue;
+        ++finite_cnt;
+        for (int d = 0; d < 3; ++d) {
+            if (p[d] < mn[d]) mn[d] = p[d];
+            if (p[d] > mx[d]) mx[d] = p[d];
+        }
+    }
+    if (finite_cnt == 0) return 0;
+    int min_b[3], max_b[3];
+    int64_t div_b[3], mul[3];
+    for (int d = 0; d < 3; ++d) {
+        min_b[d] = (int)floorf(mn[d] * inv);
+        max_b[d] = (int)floorf(mx[d] * inv);
+        div_b[d] = (int64_t)max_b[d] - (int64_t)min_b[d] + 1;
+    }
+    mul[0] = 1; mul[1] = div_b[0]; mul[2] = div_b[0] * div_b[1];
+    vp64_t *v = (vp64_t *)malloc(sizeof(vp64_t) * (size_t)finite_cnt);
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+        const float *p = xyz + 3 * (size_t)i;
+        if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) {
+            if (vox_idx) vox_idx[i] = -1;
+            continue;
+        }
+        int i0 = (int)(floorf(p[0] * inv) - (float)min_b[0]);
+        int i1 = (int)(floorf(p[1] * inv) - (float)min_b[1]);
+        int i2 = (int)(floorf(p[2] * inv) - (float)min_b[2]);
+        int64_t idx = (int64_t)i0 * mul[0] + (int64_t)i1 * mul[1] + (int64_t)i2 * mul[2];
+        if (vox_idx) vox_idx[i] = idx;
+        v[k].vox = idx;
+        v[k].pt = i;
+        ++k;
+    }
+    qsort(v, (size_t)k, sizeof(vp64_t), vp64_cmp);
+    int nout = 0;
+    for (int first = 0; first < k;) {
+        int last = first + 1;
+        while (last < k && v[last].vox == v[first].vox) ++last;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int j = first; j < last; ++j) {
+            const float *p = xyz + 3 * (size_t)v[j].pt;
+            sx += p[0]; sy += p[1]; sz += p[2];
+        }
+        float cnt = (float)(last - first);
+        out[3 * (size_t)nout + 0] = sx / cnt;
+        out[3 * (size_t)nout + 1] = sy / cnt;
+        out[3 * (size_t)nout + 2] = sz / cnt;
+        if (out_vox) out_vox[nout] = v[first].vox;
+        ++nout;
+        first = last;
+    }
+    free(v);
+    return nout;
+}

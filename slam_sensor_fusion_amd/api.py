@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libslamfusion.so")
 
 SF_ICP_REF_CPP, SF_ICP_O3D_P2P, SF_ICP_P2PLANE = 0, 1, 2
-SF_VOXEL_PCL, SF_VOXEL_O3D = 0, 1
+SF_VOXEL_PCL, SF_VOXEL_O3D, SF_VOXEL_PCL64 = 0, 1, 2
 SF_FLAG_VOXEL_OVERFLOW = 1
 SF_ICP_FLAG_FEW_CORR, SF_ICP_FLAG_SINGULAR, SF_ICP_FLAG_SHARD_STALE = 1, 2, 4
 MODES = {"ref_cpp": SF_ICP_REF_CPP, "o3d_p2p": SF_ICP_O3D_P2P, "p2plane": SF_ICP_P2PLANE}
@@ -154,15 +154,21 @@ class Cloud:
         return self
 
     def from_pointcloud2(self, msg):
-        """PointCloud2-like message (width, height, point_step, fields or x/y/z at 0/4/8, data)."""
-        n = int(msg.width) * int(msg.height)
-        offs = {"x": 0, "y": 4, "z": 8}
+        """PointCloud2-like message (width, height, point_step, row_step, is_bigendian, fields or x/y/z float32 at
+        0/4/8, data).  The buffer length, the x/y/z datatype (FLOAT32 = 7 or FLOAT64 = 8, all three alike) and the
+        endianness are checked here and again behind the C ABI."""
+        offs, types = {"x": 0, "y": 4, "z": 8}, {"x": 7, "y": 7, "z": 7}
         for f in getattr(msg, "fields", []) or []:
             if f.name in offs:
                 offs[f.name] = int(f.offset)
+                types[f.name] = int(getattr(f, "datatype", 7))
+        if len(set(types.values())) != 1:
+            raise SlamFusionError("PointCloud2 x/y/z fields have different datatypes: %r" % (types,))
         buf = np.frombuffer(msg.data, dtype=np.uint8)
-        _check(self.lib.sf_cloud_from_pointcloud2(self.h, _p(buf), C.c_int64(n), C.c_int(int(msg.point_step)),
-                                                  C.c_int(offs["x"]), C.c_int(offs["y"]), C.c_int(offs["z"])))
+        _check(self.lib.sf_cloud_from_pointcloud2_msg(self.h, _p(buf), C.c_int64(buf.size), C.c_int64(int(msg.width)), C.c_int64(int(msg.height)),
+                                                      C.c_int(int(msg.point_step)), C.c_int64(int(getattr(msg, "row_step", 0) or 0)),
+                                                      C.c_int(offs["x"]), C.c_int(offs["y"]), C.c_int(offs["z"]), C.c_int(types["x"]),
+                                                      C.c_int(int(bool(getattr(msg, "is_bigendian", False))))))
         return self
 
     def load_pcd(self, path):
@@ -239,7 +245,7 @@ class Cloud:
 
     def voxel_downsample(self, leaf=0.1, flavour="pcl"):
         flags = C.c_int(0)
-        fl = SF_VOXEL_PCL if flavour == "pcl" else SF_VOXEL_O3D
+        fl = {"pcl": SF_VOXEL_PCL, "o3d": SF_VOXEL_O3D, "pcl64": SF_VOXEL_PCL64}[flavour]
         _check(self.lib.sf_cloud_voxel_downsample(self.h, C.c_double(leaf), C.c_int(fl), C.byref(flags)))
         return flags.value
 
@@ -249,6 +255,19 @@ class Cloud:
         out = np.empty(max(n.value, 1), np.int32)
         _check(fn(self.h, _p(out), C.c_int64(len(out)), C.byref(n)))
         return out[:n.value]
+
+    def _i64(self, fn):
+        n = C.c_int64()
+        fn(self.h, None, C.c_int64(0), C.byref(n))
+        out = np.empty(max(n.value, 1), np.int64)
+        _check(fn(self.h, _p(out), C.c_int64(len(out)), C.byref(n)))
+        return out[:n.value]
+
+    def voxel_point_ids64(self):                     # after voxel_downsample(flavour="pcl64")
+        return self._i64(self.lib.sf_cloud_voxel_point_ids64)
+
+    def voxel_out_ids64(self):
+        return self._i64(self.lib.sf_cloud_voxel_out_ids64)
 
     def voxel_point_ids(self):
         return self._i32(self.lib.sf_cloud_voxel_point_ids)
@@ -319,8 +338,15 @@ class Map:
         _check(self.lib.sf_map_window_count(self.h, C.byref(n)))
         return n.value
 
-    def estimate_normals(self, radius):
-        _check(self.lib.sf_map_estimate_normals(self.h, C.c_float(radius)))
+    def estimate_normals(self, radius, covariance=False):
+        _check(self.lib.sf_map_estimate_normals_cov(self.h, C.c_float(radius), C.c_int(int(covariance))))
+
+    def download_covariances(self):
+        """[n, 6] float64: xx xy xz yy yz zz of each point's neighbourhood (original point order)."""
+        n = len(self)
+        cov = np.empty((n, 6), np.float64)
+        _check(self.lib.sf_map_download_covariances(self.h, _p(cov), C.c_int64(n), None))
+        return cov
 
     def set_normals(self, normals):
         nrm = _f32(normals).reshape(-1, 3)
@@ -583,6 +609,36 @@ def pcd_read(path):
 def pcd_write_binary(path, xyz):
     xyz = _f32(xyz).reshape(-1, 3)
     _check(load_library().sf_pcd_write_binary(str(path).encode(), _p(xyz), C.c_int64(len(xyz))))
+
+
+class MapDataSaver:
+    """sf_recorder: the file writers of mapping/src/map_data_save_node.cpp (tiles + the two text logs)."""
+
+    def __init__(self, map_data_path):
+        self.lib = load_library()
+        self.lib.sf_recorder_compass_yaw.restype = C.c_double
+        self.h = C.c_void_p()
+        _check(self.lib.sf_recorder_create(str(map_data_path).encode(), C.byref(self.h)))
+        self.current_compass_yaw = 0.0
+
+    def compassCallback(self, hdg_deg):
+        self.current_compass_yaw = float(self.lib.sf_recorder_compass_yaw(C.c_double(hdg_deg)))
+
+    def mappingCallback(self, xyz, odom_xyz, lat, lon, alt):
+        xyz, o = _f32(xyz).reshape(-1, 3), _f64(odom_xyz).reshape(3)
+        _check(self.lib.sf_recorder_add(self.h, _p(xyz), C.c_int64(len(xyz)), _p(o), C.c_double(lat), C.c_double(lon), C.c_double(alt),
+                                        C.c_double(self.current_compass_yaw)))
+
+    def onShutdown(self):
+        _check(self.lib.sf_recorder_shutdown(self.h))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.sf_recorder_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 class GlobalMapFramesManager:

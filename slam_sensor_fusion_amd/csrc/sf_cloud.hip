@@ -9,6 +9,8 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <atomic>
+
 namespace sf {
 static thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...)
@@ -19,6 +21,11 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 int ensure_scratch(sf_ctx *ctx, size_t bytes) { return ctx->scratch.reserve(bytes); }
+uint64_t next_generation()
+{
+    static std::atomic<uint64_t> g{0};
+    return ++g;
+}
 } // namespace sf
 
 extern "C" int sf_version(void) { return SF_VERSION; }
@@ -118,7 +125,7 @@ extern "C" void sf_cloud_destroy(sf_cloud *c)
     if (!c) return;
     hipError_t e = hipStreamSynchronize(c->ctx->stream);
     (void)e;
-    c->xyz.release(); c->last_idx.release(); c->vox_point_ids.release();
+    c->xyz.release(); c->spare.release(); c->flags.release(); c->raw.release(); c->last_idx.release(); c->vox_point_ids.release();
     c->vox_out_ids.release(); c->vox_out_means.release();
     sf_ctx *ctx = c->ctx;
     delete c;
@@ -288,7 +295,7 @@ int compact_cloud(sf_cloud *c, const uint8_t *d_flags)
     int64_t nb = div_up(n, CB);
     SF_TRY(ctx->scratch2.reserve(sizeof(uint32_t) * (size_t)(nb + 1)));
     uint32_t *bc = ctx->scratch2.as<uint32_t>();
-    DevBuf out;
+    DevBuf &out = c->spare; // ping-pong with xyz: no hipMalloc / hipFree per crop
     SF_TRY(out.reserve(sizeof(float) * 3 * (size_t)n));
     SF_TRY(c->last_idx.reserve(sizeof(int32_t) * (size_t)n));
     hipLaunchKernelGGL(k_count_flags, dim3((unsigned)nb), dim3(CB), 0, ctx->stream, d_flags, n, bc);
@@ -296,10 +303,9 @@ int compact_cloud(sf_cloud *c, const uint8_t *d_flags)
     hipLaunchKernelGGL(k_scatter_flags, dim3((unsigned)nb), dim3(CB), 0, ctx->stream, d_flags, n, bc, c->xyz.as<float>(), out.as<float>(), c->last_idx.as<int32_t>());
     uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
     SF_HIP(hipMemcpyAsync(h, bc + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SF_HIP(hipStreamSynchronize(ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream)); // the kept count is a host value (sf_cloud_size)
     SF_HIP(hipGetLastError());
-    c->xyz.release();
-    c->xyz = out;
+    c->xyz.swap(out);
     c->n = h[0];
     c->n_last_idx = c->n;
     return SF_OK;
@@ -413,13 +419,12 @@ extern "C" int sf_cloud_subsample(sf_cloud *c, int step)
         return SF_OK;
     }
     int64_t n_out = sf::div_up(c->n, step);
-    sf::DevBuf out;
+    sf::DevBuf &out = c->spare;
     SF_TRY(out.reserve(sizeof(float) * 3 * (size_t)n_out));
     SF_TRY(c->last_idx.reserve(sizeof(int32_t) * (size_t)n_out));
     hipLaunchKernelGGL(k_subsample, dim3(nblk(n_out)), dim3(256), 0, c->ctx->stream, c->xyz.as<float>(), n_out, step, out.as<float>(), c->last_idx.as<int32_t>());
-    SF_HIP(hipStreamSynchronize(c->ctx->stream));
-    c->xyz.release();
-    c->xyz = out;
+    SF_HIP(hipGetLastError());
+    c->xyz.swap(out); // stream-ordered: the old buffer is only reused by later work on the same stream
     c->n = n_out;
     c->n_last_idx = n_out;
     return SF_OK;
@@ -433,7 +438,8 @@ extern "C" int sf_cloud_crop_radius(sf_cloud *c, const float center[3], double r
     int64_t n = c->n;
     if (n == 0) { c->n_last_idx = 0; return SF_OK; }
     const float r2 = (float)(radius * radius);
-    sf::DevBuf flags, d2;
+    sf::DevBuf &flags = c->flags;
+    sf::DevBuf d2;
     SF_TRY(flags.reserve((size_t)n));
     if (sorted) SF_TRY(d2.reserve(sizeof(float) * (size_t)n));
     hipLaunchKernelGGL(k_flag_radius, dim3(nblk(n)), dim3(256), 0, ctx->stream, c->xyz.as<float>(), n, center[0], center[1], center[2], r2,
@@ -462,14 +468,15 @@ extern "C" int sf_cloud_crop_radius(sf_cloud *c, const float center[3], double r
                 hipLaunchKernelGGL(k_gather_by_key, dim3(nblk(k)), dim3(256), 0, ctx->stream, orig.as<float>(), keys2.as<uint64_t>(), k, out.as<float>(), c->last_idx.as<int32_t>());
                 hipError_t e2 = hipStreamSynchronize(ctx->stream);
                 if (e2 != hipSuccess) { sf::set_error("sync: %s", hipGetErrorString(e2)); rc = SF_ERR_HIP; }
-                else { c->xyz.release(); c->xyz = out; out.p = nullptr; }
+                else c->xyz.swap(out);
             }
         }
         keys.release(); keys2.release(); out.release();
     }
-    hipError_t es = hipStreamSynchronize(ctx->stream);
-    (void)es;
-    flags.release(); d2.release(); orig.release();
+    if (sorted) { // d2 / orig are freed on return
+        hipError_t es = hipStreamSynchronize(ctx->stream);
+        (void)es;
+    }
     return rc;
 }
 
@@ -478,12 +485,10 @@ extern "C" int sf_cloud_remove_floor(sf_cloud *c)
     SF_CHECK(c, SF_ERR_INVALID, "bad arguments");
     SF_HIP(hipSetDevice(c->ctx->device));
     if (c->n == 0) { c->n_last_idx = 0; return SF_OK; }
-    sf::DevBuf flags;
+    sf::DevBuf &flags = c->flags;
     SF_TRY(flags.reserve((size_t)c->n));
     hipLaunchKernelGGL(k_flag_floor, dim3(nblk(c->n)), dim3(256), 0, c->ctx->stream, c->xyz.as<float>(), c->n, flags.as<uint8_t>());
-    int rc = sf::compact_cloud(c, flags.as<uint8_t>());
-    flags.release();
-    return rc;
+    return sf::compact_cloud(c, flags.as<uint8_t>());
 }
 
 extern "C" int sf_cloud_crop_aabb(sf_cloud *c, const double lo[3], const double hi[3])
@@ -493,12 +498,10 @@ extern "C" int sf_cloud_crop_aabb(sf_cloud *c, const double lo[3], const double 
     if (c->n == 0) { c->n_last_idx = 0; return SF_OK; }
     Box b;
     for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d]; b.hi[d] = hi[d]; }
-    sf::DevBuf flags;
+    sf::DevBuf &flags = c->flags;
     SF_TRY(flags.reserve((size_t)c->n));
     hipLaunchKernelGGL(k_flag_aabb, dim3(nblk(c->n)), dim3(256), 0, c->ctx->stream, c->xyz.as<float>(), c->n, b, flags.as<uint8_t>());
-    int rc = sf::compact_cloud(c, flags.as<uint8_t>());
-    flags.release();
-    return rc;
+    return sf::compact_cloud(c, flags.as<uint8_t>());
 }
 
 extern "C" int sf_cloud_crop_obb(sf_cloud *c, const double center[3], const double R[9], const double extent[3])
@@ -509,12 +512,10 @@ extern "C" int sf_cloud_crop_obb(sf_cloud *c, const double center[3], const doub
     Obb o;
     for (int d = 0; d < 3; ++d) { o.c[d] = center[d]; o.half[d] = extent[d] / 2; }
     for (int k = 0; k < 9; ++k) o.R[k] = R[k];
-    sf::DevBuf flags;
+    sf::DevBuf &flags = c->flags;
     SF_TRY(flags.reserve((size_t)c->n));
     hipLaunchKernelGGL(k_flag_obb, dim3(nblk(c->n)), dim3(256), 0, c->ctx->stream, c->xyz.as<float>(), c->n, o, flags.as<uint8_t>());
-    int rc = sf::compact_cloud(c, flags.as<uint8_t>());
-    flags.release();
-    return rc;
+    return sf::compact_cloud(c, flags.as<uint8_t>());
 }
 
 extern "C" int sf_cloud_transform(sf_cloud *c, const float T[16])
@@ -546,8 +547,7 @@ extern "C" int sf_cloud_append(sf_cloud *dst, const sf_cloud *src)
         SF_TRY(nb.reserve(b0 + b1 + ((b0 + b1) >> 1)));
         if (b0) SF_HIP(hipMemcpyAsync(nb.p, dst->xyz.p, b0, hipMemcpyDeviceToDevice, s));
         SF_HIP(hipStreamSynchronize(s));
-        dst->xyz.release();
-        dst->xyz = nb;
+        dst->xyz.swap(nb); // nb (the old allocation) is freed on scope exit
     }
     SF_HIP(hipMemcpyAsync(static_cast<char *>(dst->xyz.p) + b0, src->xyz.p, b1, hipMemcpyDeviceToDevice, s));
     dst->n += src->n;
@@ -558,7 +558,7 @@ extern "C" int sf_cloud_append(sf_cloud *dst, const sf_cloud *src)
 
 // ------------------------------------------------------------------ bounds of the finite points
 namespace {
-struct MinMaxDev { float mn[3], mx[3]; unsigned long long cnt; };
+using sf::MinMaxDev;
 
 __global__ __launch_bounds__(256) void k_minmax_partial(const float *__restrict__ xyz, int64_t n, MinMaxDev *__restrict__ part)
 {
@@ -598,31 +598,46 @@ __global__ __launch_bounds__(256) void k_minmax_partial(const float *__restrict_
     }
 }
 
-__global__ void k_minmax_final(MinMaxDev *__restrict__ part, int nb)
+__global__ void k_minmax_final(const MinMaxDev *__restrict__ part, int nb, MinMaxDev *__restrict__ out)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    MinMaxDev r = part[0];
-    for (int k = 1; k < nb; ++k) {
+    MinMaxDev r;
+    for (int d = 0; d < 3; ++d) { r.mn[d] = INFINITY; r.mx[d] = -INFINITY; }
+    r.cnt = 0;
+    for (int k = 0; k < nb; ++k) {
         for (int d = 0; d < 3; ++d) { r.mn[d] = fminf(r.mn[d], part[k].mn[d]); r.mx[d] = fmaxf(r.mx[d], part[k].mx[d]); }
         r.cnt += part[k].cnt;
     }
-    part[nb] = r;
+    if (r.cnt == 0)
+        for (int d = 0; d < 3; ++d) { r.mn[d] = 0.0f; r.mx[d] = 0.0f; }
+    *out = r;
 }
 } // namespace
 
 namespace sf {
+int cloud_minmax_enqueue(sf_ctx *ctx, const float *d_xyz, int64_t n, MinMaxDev *d_out)
+{
+    const int nb = n > 0 ? (int)std::min<int64_t>(1024, div_up(n, 256)) : 0;
+    SF_TRY(ctx->scratch2.reserve(sizeof(MinMaxDev) * (size_t)(nb + 1)));
+    MinMaxDev *part = ctx->scratch2.as<MinMaxDev>();
+    if (nb > 0) hipLaunchKernelGGL(k_minmax_partial, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, part);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, ctx->stream, part, nb, d_out);
+    SF_HIP(hipGetLastError());
+    return SF_OK;
+}
+
 int cloud_minmax(sf_ctx *ctx, const float *d_xyz, int64_t n, MinMaxHost *out)
 {
     for (int d = 0; d < 3; ++d) { out->mn[d] = 0; out->mx[d] = 0; }
     out->n_finite = 0;
     if (n <= 0) return SF_OK;
-    int nb = (int)std::min<int64_t>(1024, div_up(n, 256));
-    SF_TRY(ctx->scratch2.reserve(sizeof(MinMaxDev) * (size_t)(nb + 1)));
+    const int nb = (int)std::min<int64_t>(1024, div_up(n, 256));
+    SF_TRY(ctx->scratch2.reserve(sizeof(MinMaxDev) * (size_t)(nb + 2)));
     MinMaxDev *part = ctx->scratch2.as<MinMaxDev>();
-    hipLaunchKernelGGL(k_minmax_partial, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, part);
-    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, ctx->stream, part, nb);
+    SF_TRY(cloud_minmax_enqueue(ctx, d_xyz, n, part + nb + 1));
+    part = ctx->scratch2.as<MinMaxDev>();
     MinMaxDev h;
-    SF_HIP(hipMemcpyAsync(&h, part + nb, sizeof(MinMaxDev), hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipMemcpyAsync(&h, part + nb + 1, sizeof(MinMaxDev), hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
     for (int d = 0; d < 3; ++d) { out->mn[d] = h.mn[d]; out->mx[d] = h.mx[d]; }
     out->n_finite = (int64_t)h.cnt;
@@ -635,35 +650,60 @@ int cloud_minmax(sf_ctx *ctx, const float *d_xyz, int64_t n, MinMaxHost *out)
 // (localization_python/.../localization_node.py:106-111) on the device: the raw message buffer
 // is uploaded once and the x, y, z float32 fields are gathered from their byte offsets.
 namespace {
-__global__ void k_unpack_pc2(const uint8_t *__restrict__ raw, int64_t n, int point_step, int ox, int oy, int oz, float *__restrict__ xyz)
+// point i lives at row (i / width) * row_step + (i % width) * point_step; fields are read byte-wise (they need
+// not be aligned in the message); F64: rounded to float32 like the field mapping of pcl::fromROSMsg
+template <bool F64>
+__global__ void k_unpack_pc2(const uint8_t *__restrict__ raw, int64_t n, int64_t width, int point_step, int64_t row_step, int ox, int oy, int oz, float *__restrict__ xyz)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint8_t *p = raw + (size_t)i * point_step;
-    auto rd = [&](int off) -> float { // byte-wise: fields need not be 4-byte aligned in the message
-        uint32_t v = (uint32_t)p[off] | ((uint32_t)p[off + 1] << 8) | ((uint32_t)p[off + 2] << 16) | ((uint32_t)p[off + 3] << 24);
-        return __uint_as_float(v);
+    const uint8_t *p = raw + (size_t)(i / width) * (size_t)row_step + (size_t)(i % width) * (size_t)point_step;
+    auto rd = [&](int off) -> float {
+        uint32_t lo = (uint32_t)p[off] | ((uint32_t)p[off + 1] << 8) | ((uint32_t)p[off + 2] << 16) | ((uint32_t)p[off + 3] << 24);
+        if (!F64) return __uint_as_float(lo);
+        uint32_t hi = (uint32_t)p[off + 4] | ((uint32_t)p[off + 5] << 8) | ((uint32_t)p[off + 6] << 16) | ((uint32_t)p[off + 7] << 24);
+        return (float)__hiloint2double((int)hi, (int)lo);
     };
     xyz[3 * i] = rd(ox); xyz[3 * i + 1] = rd(oy); xyz[3 * i + 2] = rd(oz);
 }
 } // namespace
 
-extern "C" int sf_cloud_from_pointcloud2(sf_cloud *c, const void *data, int64_t n_points, int point_step, int off_x, int off_y, int off_z)
+extern "C" int sf_cloud_from_pointcloud2_msg(sf_cloud *c, const void *data, int64_t data_bytes, int64_t width, int64_t height, int point_step, int64_t row_step,
+                                             int off_x, int off_y, int off_z, int datatype, int is_bigendian)
 {
-    SF_CHECK(c && n_points >= 0 && (data || n_points == 0), SF_ERR_INVALID, "bad arguments");
-    SF_CHECK(point_step >= 12 && off_x >= 0 && off_y >= 0 && off_z >= 0 && off_x + 4 <= point_step && off_y + 4 <= point_step && off_z + 4 <= point_step,
+    SF_CHECK(c && width >= 0 && height >= 0 && data_bytes >= 0, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(!is_bigendian, SF_ERR_INVALID, "big-endian PointCloud2 payloads are not supported");
+    SF_CHECK(datatype == SF_PC2_FLOAT32 || datatype == SF_PC2_FLOAT64, SF_ERR_INVALID, "x/y/z datatype %d: FLOAT32 (7) or FLOAT64 (8) expected", datatype);
+    const int fsz = datatype == SF_PC2_FLOAT64 ? 8 : 4;
+    SF_CHECK(point_step >= 3 * fsz && off_x >= 0 && off_y >= 0 && off_z >= 0 && off_x + fsz <= point_step && off_y + fsz <= point_step && off_z + fsz <= point_step,
              SF_ERR_INVALID, "field offsets do not fit point_step %d", point_step);
+    SF_CHECK(height == 0 || width < ((int64_t)1 << 31) / height, SF_ERR_OVERFLOW, "too many points");
+    const int64_t n_points = width * height;
+    if (row_step == 0) row_step = width * (int64_t)point_step;
+    SF_CHECK(row_step >= width * (int64_t)point_step, SF_ERR_INVALID, "row_step %lld is shorter than width x point_step", (long long)row_step);
+    const int64_t need = n_points == 0 ? 0 : (height - 1) * row_step + width * (int64_t)point_step;
+    SF_CHECK(data_bytes >= need && (data || need == 0), SF_ERR_INVALID, "PointCloud2 data holds %lld bytes, %lld x %lld points need %lld", (long long)data_bytes,
+             (long long)width, (long long)height, (long long)need);
     SF_HIP(hipSetDevice(c->ctx->device));
     SF_TRY(c->xyz.reserve(sizeof(float) * 3 * (size_t)(n_points > 0 ? n_points : 1)));
     if (n_points > 0) {
-        sf::DevBuf raw;
-        SF_TRY(raw.reserve((size_t)n_points * (size_t)point_step));
-        SF_HIP(hipMemcpyAsync(raw.p, data, (size_t)n_points * (size_t)point_step, hipMemcpyHostToDevice, c->ctx->stream));
-        hipLaunchKernelGGL(k_unpack_pc2, dim3(nblk(n_points)), dim3(256), 0, c->ctx->stream, raw.as<uint8_t>(), n_points, point_step, off_x, off_y, off_z, c->xyz.as<float>());
-        SF_HIP(hipStreamSynchronize(c->ctx->stream));
-        raw.release();
+        SF_TRY(c->raw.reserve((size_t)need)); // persistent staging: no hipMalloc / hipFree per scan
+        // pageable source: the copy is staged by the runtime and the host buffer is free on return
+        SF_HIP(hipMemcpyAsync(c->raw.p, data, (size_t)need, hipMemcpyHostToDevice, c->ctx->stream));
+        if (datatype == SF_PC2_FLOAT64)
+            hipLaunchKernelGGL(k_unpack_pc2<true>, dim3(nblk(n_points)), dim3(256), 0, c->ctx->stream, c->raw.as<uint8_t>(), n_points, width, point_step, row_step, off_x, off_y, off_z, c->xyz.as<float>());
+        else
+            hipLaunchKernelGGL(k_unpack_pc2<false>, dim3(nblk(n_points)), dim3(256), 0, c->ctx->stream, c->raw.as<uint8_t>(), n_points, width, point_step, row_step, off_x, off_y, off_z, c->xyz.as<float>());
+        SF_HIP(hipGetLastError());
     }
     c->n = n_points;
     cloud_reset_meta(c);
     return SF_OK;
+}
+
+// the unchecked legacy form: n_points tightly packed points of point_step bytes (the caller vouches for the buffer length)
+extern "C" int sf_cloud_from_pointcloud2(sf_cloud *c, const void *data, int64_t n_points, int point_step, int off_x, int off_y, int off_z)
+{
+    SF_CHECK(n_points >= 0 && point_step > 0, SF_ERR_INVALID, "bad arguments");
+    return sf_cloud_from_pointcloud2_msg(c, data, n_points * (int64_t)point_step, n_points, n_points > 0 ? 1 : 0, point_step, 0, off_x, off_y, off_z, SF_PC2_FLOAT32, 0);
 }

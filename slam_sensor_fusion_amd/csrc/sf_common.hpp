@@ -42,9 +42,15 @@ void set_error(const char *fmt, ...);
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    uint32_t epoch = 0; // bumped whenever the allocation (hence the pointer) changes: captured hipGraphs key on it
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); } // error paths between reserve() and release() do not leak
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return SF_OK;
+        ++epoch;
         if (p) {
             hipError_t e = hipFree(p);
             (void)e;
@@ -66,9 +72,17 @@ struct DevBuf {
         if (p) {
             hipError_t e = hipFree(p);
             (void)e;
+            ++epoch;
         }
         p = nullptr;
         cap = 0;
+    }
+    // exchange the allocations of two buffers (ping-pong outputs without a hipMalloc / hipFree per call)
+    void swap(DevBuf &o)
+    {
+        void *tp = p; p = o.p; o.p = tp;
+        size_t tc = cap; cap = o.cap; o.cap = tc;
+        ++epoch; ++o.epoch;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
@@ -94,9 +108,13 @@ struct sf_cloud {
     sf_ctx *ctx = nullptr;
     sf::DevBuf xyz;       // float[n][3]
     int64_t n = 0;
+    sf::DevBuf spare;     // output of the next crop / subsample / sort (swapped with xyz: no allocation per scan)
+    sf::DevBuf flags;     // predicate flags of the crops
+    sf::DevBuf raw;       // persistent staging of sf_cloud_from_pointcloud2 / sf_cloud_upload_f64 (no allocation per scan)
     sf::DevBuf last_idx;  // int32 indices kept by the last crop/subsample
     int64_t n_last_idx = -1;
     // voxel introspection (parity tests)
+    bool vox_wide = false; // the last downsample kept int64 ids (SF_VOXEL_PCL64)
     sf::DevBuf vox_point_ids; int64_t n_vox_point_vals = 0;
     sf::DevBuf vox_out_ids;   int64_t n_vox_out_vals = 0;
     sf::DevBuf vox_out_means; int64_t n_vox_out_pts = 0; // float64 means (O3D flavour)
@@ -127,8 +145,10 @@ struct SfGrid {
 struct sf_map {
     sf_ctx *ctx = nullptr;
     sf::DevBuf pts4, nrm4, cell_start, keys, vals, keys2, vals2, inv_perm;
+    sf::DevBuf cov6;   // optional: the 6 unique entries of each point's neighbourhood covariance (sorted order), sf_map_estimate_normals
     int64_t n = 0;
-    bool built = false, has_normals = false;
+    bool built = false, has_normals = false, has_cov = false;
+    uint64_t generation = 0; // process-unique stamp of the index contents (build / normals): captured hipGraphs key on it
     SfGrid grid{};
     SfWindow window{};
 };
@@ -137,10 +157,14 @@ namespace sf {
 // device-side helpers implemented in sf_cloud.hip, used across TUs
 int compact_cloud(sf_cloud *c, const uint8_t *d_flags);
 int ensure_scratch(sf_ctx *ctx, size_t bytes);
+uint64_t next_generation();
 // children keep their context alive: any destruction order is safe
 void ctx_retain(sf_ctx *ctx);
 void ctx_release(sf_ctx *ctx);
 struct MinMaxHost { float mn[3], mx[3]; int64_t n_finite; };
+struct MinMaxDev { float mn[3], mx[3]; unsigned long long cnt; }; // zeros when no point is finite
+// the same reduction left on the device (no host synchronisation): *d_out is written on the stream
+int cloud_minmax_enqueue(sf_ctx *ctx, const float *d_xyz, int64_t n, MinMaxDev *d_out);
 // min/max over the finite points of a device AoS cloud (synchronises the stream)
 int cloud_minmax(sf_ctx *ctx, const float *d_xyz, int64_t n, MinMaxHost *out);
 } // namespace sf

@@ -963,7 +963,7 @@ __global__ __launch_bounds__(RBLK) void k_reduce_only(IcpState *__restrict__ st,
 }
 
 template <int MODE>
-__global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict__ xchg, int n_src, int K, int batch, ScanBox box, float margin)
+__global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict__ xchg, int n_src, int K, int batch, const ScanBox *__restrict__ boxp, float margin)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -977,7 +977,7 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
     for (int c = 0; c < NREC; ++c) S->rec[c] = rec[c];
     if (MODE == 1) solve_o3d(S, rec, n_src, 0, K);
     else solve_plane(S, rec, n_src, K);
-    if (margin > 0.0f && !S->done) own_check_motion(S, box, margin); // sharded path only
+    if (margin > 0.0f && !S->done) own_check_motion(S, *boxp, margin); // sharded path only (the box of the source batch, computed on the device)
 }
 
 // ------------------------------------------------------------------ REF_CPP mode
@@ -1161,14 +1161,28 @@ struct sf_icp {
     int64_t own_total = 0;                            // owned-query candidates of this rank (all scans)
     float own_margin = 1.0f;                          // sf_icp_set_shard_margin
     int own_nblocks = 1;                              // workgroups per scan on the sharded path (largest scan)
-    ScanBox box{};                           // bounding box of the source batch (finite points)
+    sf::DevBuf d_box;                        // sf::MinMaxDev: bounding box of the source batch (finite points), left on the device
+    sf::DevBuf stage;                        // persistent upload staging of sf_icp_set_source* (AoS)
     int last_mode = 0;
     // graph
     bool use_graph = false;
     hipGraphExec_t graph_exec = nullptr;
-    int graph_mode = -1, graph_iters = -1, graph_batch = -1, graph_window = -1, graph_ordered = -1;
-    int64_t graph_n = -1;
-    const void *graph_map = nullptr;
+    // everything a captured launch list bakes in: kernel arguments passed by value (thresholds, IcpParams, the
+    // SfGrid geometry and pointers) and the addresses of this object's buffers.  A replay is only valid while all of
+    // it is unchanged; sf_map stamps every build / normals pass with a process-unique generation, DevBuf counts its
+    // reallocations (epoch).
+    struct GraphKey {
+        int mode = -1, iters = -1, batch = -1, window = -1, ordered = -1, reuse = -1;
+        int64_t n = -1;
+        const void *map = nullptr;
+        uint64_t map_generation = 0, epochs = 0;
+        float max_corr = 0, accept = 0, eps = 0;
+        bool operator==(const GraphKey &o) const
+        {
+            return mode == o.mode && iters == o.iters && batch == o.batch && window == o.window && ordered == o.ordered && reuse == o.reuse && n == o.n && map == o.map &&
+                   map_generation == o.map_generation && epochs == o.epochs && max_corr == o.max_corr && accept == o.accept && eps == o.eps;
+        }
+    } graph_key;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> ev;
@@ -1281,9 +1295,11 @@ int icp_set_source_device_aos(sf_icp *icp, const float *d_aos, int64_t n, int ba
         hipLaunchKernelGGL(k_soa_from_aos, dim3(nblk(total)), dim3(256), 0, icp->ctx->stream, d_aos, total, soa(icp->X0, total, 0), soa(icp->X0, total, 1),
                            soa(icp->X0, total, 2), icp->X0r.as<float4>());
     SF_HIP(hipGetLastError());
-    sf::MinMaxHost mm; // bounding box of the batch: the sharded path's list-rebuild rule needs it
-    SF_TRY(sf::cloud_minmax(icp->ctx, d_aos, total, &mm));
-    for (int d = 0; d < 3; ++d) { icp->box.lo[d] = mm.mn[d]; icp->box.hi[d] = mm.mx[d]; }
+    // bounding box of the batch (the sharded path's list-rebuild rule reads it in k_solve_only): reduced on the
+    // device and left there -- no host synchronisation per scan
+    static_assert(sizeof(ScanBox) <= sizeof(sf::MinMaxDev), "ScanBox is the head of MinMaxDev");
+    SF_TRY(icp->d_box.reserve(sizeof(sf::MinMaxDev)));
+    SF_TRY(sf::cloud_minmax_enqueue(icp->ctx, d_aos, total, icp->d_box.as<sf::MinMaxDev>()));
     icp->have_source = true;
     return SF_OK;
 }
@@ -1317,6 +1333,20 @@ void prof_collect(sf_icp *icp)
         if (hipEventElapsedTime(&ms, icp->ev[k], icp->ev[k + 1]) == hipSuccess) { icp->prof_ms += ms; icp->prof_launches += 1; }
     }
     icp->ev_used = 0;
+}
+
+sf_icp::GraphKey graph_key_now(const sf_icp *icp, int mode)
+{
+    sf_icp::GraphKey k;
+    k.mode = mode; k.iters = icp->prm.num_iters; k.batch = icp->batch; k.window = icp->map->window.kind; k.ordered = (int)icp->ordered; k.reuse = (int)icp->reuse;
+    k.n = icp->n;
+    k.map = (const void *)icp->map;
+    k.map_generation = icp->map->generation;
+    k.max_corr = icp->prm.max_corr; k.accept = icp->prm.accept; k.eps = icp->prm.eps;
+    const sf::DevBuf *bufs[] = {&icp->X0, &icp->X0r, &icp->X, &icp->Xq, &icp->qcache, &icp->corr, &icp->state, &icp->partials, &icp->d_box,
+                                &icp->map->pts4, &icp->map->nrm4, &icp->map->cell_start};
+    for (const sf::DevBuf *b : bufs) k.epochs = k.epochs * 1000003ull + b->epoch;
+    return k;
 }
 
 float o3d_thr(const sf_icp *icp) { return (float)((double)icp->prm.max_corr * (double)icp->prm.max_corr); }
@@ -1465,7 +1495,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     if (icp->graph_exec) { e = hipGraphExecDestroy(icp->graph_exec); (void)e; }
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
     icp->X0.release(); icp->X0r.release(); icp->qcache.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
-    icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
+    icp->d_box.release(); icp->stage.release(); icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
     sf_ctx *ctx = icp->ctx;
@@ -1511,13 +1541,12 @@ extern "C" int sf_icp_set_source_batch(sf_icp *icp, const float *xyz, int64_t n_
     SF_HIP(hipSetDevice(icp->ctx->device));
     std::vector<double> keep = icp->inits;
     const int64_t total = n_per_scan * batch;
-    sf::DevBuf tmp;
-    SF_TRY(tmp.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
-    if (total > 0) SF_HIP(hipMemcpyAsync(tmp.p, xyz, sizeof(float) * 3 * (size_t)total, hipMemcpyHostToDevice, icp->ctx->stream));
-    int rc = icp_set_source_device_aos(icp, tmp.as<float>(), n_per_scan, batch);
-    hipError_t e = hipStreamSynchronize(icp->ctx->stream);
-    tmp.release();
-    if (rc == SF_OK && e != hipSuccess) { sf::set_error("sync: %s", hipGetErrorString(e)); rc = SF_ERR_HIP; }
+    // persistent staging buffer, no allocation and no host synchronisation per scan: a copy from pageable host
+    // memory is staged by the runtime before hipMemcpyAsync returns (the caller may reuse xyz at once); pinned
+    // host memory is read asynchronously, stream-ordered -- then the caller owns the usual lifetime rule
+    SF_TRY(icp->stage.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
+    if (total > 0) SF_HIP(hipMemcpyAsync(icp->stage.p, xyz, sizeof(float) * 3 * (size_t)total, hipMemcpyHostToDevice, icp->ctx->stream));
+    int rc = icp_set_source_device_aos(icp, icp->stage.as<float>(), n_per_scan, batch);
     if (batch == 1 && keep.size() >= 16) icp->inits.assign(keep.begin(), keep.begin() + 16); // setters are order independent
     return rc;
 }
@@ -1593,17 +1622,16 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     launch_state_init(icp);
     SF_TRY(order_queries(icp, mode)); // plain launches ahead of the (replayed) iteration graph
     if (mode != SF_ICP_REF_CPP) SF_TRY(reuse_reset(icp, icp->n * icp->batch));
-    if (icp->use_graph && !icp->profiling) {
-        const bool hit = icp->graph_exec && icp->graph_mode == mode && icp->graph_iters == icp->prm.num_iters && icp->graph_batch == icp->batch &&
-                         icp->graph_n == icp->n && icp->graph_map == (const void *)icp->map->grid.pts && icp->graph_window == icp->map->window.kind &&
-                         icp->map->window.kind == 0 && !icp->shard && icp->graph_ordered == (int)icp->ordered;
+    if (icp->use_graph && !icp->profiling && icp->map->window.kind == 0) { // a window travels by value and moves with the pose: plain launches
+        if (mode == SF_ICP_REF_CPP) { // buffers must exist before capture (and before the key is formed)
+            const int64_t total = icp->n * icp->batch;
+            SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
+            SF_TRY(icp->corr.reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1)));
+        }
+        const sf_icp::GraphKey key = graph_key_now(icp, mode);
+        const bool hit = icp->graph_exec && key == icp->graph_key;
         if (!hit) {
             if (icp->graph_exec) { hipError_t e = hipGraphExecDestroy(icp->graph_exec); (void)e; icp->graph_exec = nullptr; }
-            if (mode == SF_ICP_REF_CPP) { // buffers must exist before capture
-                const int64_t total = icp->n * icp->batch;
-                SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
-                SF_TRY(icp->corr.reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1)));
-            }
             hipGraph_t graph = nullptr;
             SF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             int rc = enqueue_align(icp, mode);
@@ -1614,8 +1642,7 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
             hipError_t e2 = hipGraphDestroy(graph);
             (void)e2;
             SF_CHECK(e == hipSuccess, SF_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-            icp->graph_mode = mode; icp->graph_iters = icp->prm.num_iters; icp->graph_batch = icp->batch; icp->graph_n = icp->n;
-            icp->graph_map = (const void *)icp->map->grid.pts; icp->graph_window = icp->map->window.kind; icp->graph_ordered = (int)icp->ordered;
+            icp->graph_key = key;
         }
         SF_HIP(hipGraphLaunch(icp->graph_exec, s));
         return SF_OK;
@@ -1797,9 +1824,9 @@ extern "C" int sf_icp_step_end(sf_icp *icp, int mode, int last)
     hipStream_t s = icp->ctx->stream;
     const int K = icp->prm.num_iters;
     if (mode == SF_ICP_O3D_P2P)
-        hipLaunchKernelGGL(k_solve_only<1>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->box, icp->shard ? icp->own_margin : 0.0f);
+        hipLaunchKernelGGL(k_solve_only<1>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->d_box.as<ScanBox>(), icp->shard ? icp->own_margin : 0.0f);
     else
-        hipLaunchKernelGGL(k_solve_only<2>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->box, icp->shard ? icp->own_margin : 0.0f);
+        hipLaunchKernelGGL(k_solve_only<2>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->d_box.as<ScanBox>(), icp->shard ? icp->own_margin : 0.0f);
     SF_HIP(hipGetLastError());
     return SF_OK;
 }

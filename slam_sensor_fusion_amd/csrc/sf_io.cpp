@@ -14,14 +14,35 @@
 #include <cstdlib>
 #include <dirent.h>
 #include <fstream>
+#include <iomanip>
 #include <sstream>
 #include <string>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
 
 namespace {
 
 struct PcdField { std::string name; int size = 4; char type = 'F'; int count = 1; int offset = 0; };
+constexpr int64_t PCD_MAX_POINTS = (int64_t)1 << 31;          // far beyond any tile the recorder writes
+constexpr int64_t PCD_MAX_BYTES = (int64_t)64 << 30;          // raw payload cap (host memory)
+
+// nothing may unwind through the extern "C" boundary (a ctypes / ROS host would std::terminate)
+template <class F> int guarded(F &&fn)
+{
+    try {
+        return fn();
+    } catch (const std::bad_alloc &) {
+        sf::set_error("out of host memory");
+        return SF_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        sf::set_error("I/O failure: %s", e.what());
+        return SF_ERR_INVALID;
+    } catch (...) {
+        sf::set_error("I/O failure");
+        return SF_ERR_INVALID;
+    }
+}
 
 double read_scalar(const unsigned char *p, const PcdField &f)
 {
@@ -77,6 +98,7 @@ int pcd_read(const std::string &path, std::vector<float> &xyz)
     SF_CHECK(f.is_open(), SF_ERR_INVALID, "cannot open %s", path.c_str());
     std::vector<PcdField> fields;
     int64_t width = 0, height = 1, points = -1;
+    bool have_points = false;
     std::string data_kind, line;
     while (std::getline(f, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -90,20 +112,31 @@ int pcd_read(const std::string &path, std::vector<float> &xyz)
         else if (key == "COUNT") { for (auto &pf : fields) is >> pf.count; }
         else if (key == "WIDTH") is >> width;
         else if (key == "HEIGHT") is >> height;
-        else if (key == "POINTS") is >> points;
+        else if (key == "POINTS") { is >> points; have_points = !is.fail(); }
         else if (key == "DATA") { is >> data_kind; break; }
     }
     SF_CHECK(!fields.empty() && !data_kind.empty(), SF_ERR_INVALID, "%s: not a PCD file", path.c_str());
-    if (points < 0) points = width * height;
-    int step = 0, ix = -1, iy = -1, iz = -1;
+    // the header is untrusted input: every number that sizes a buffer or an offset is checked
+    SF_CHECK(width >= 0 && height >= 0 && (height == 0 || width <= PCD_MAX_POINTS / height), SF_ERR_INVALID, "%s: bad WIDTH / HEIGHT", path.c_str());
+    if (!have_points) points = width * height;
+    SF_CHECK(points >= 0 && points <= PCD_MAX_POINTS, SF_ERR_INVALID, "%s: bad POINTS %lld", path.c_str(), (long long)points);
+    int64_t step = 0;
+    int ix = -1, iy = -1, iz = -1;
     for (size_t k = 0; k < fields.size(); ++k) {
-        fields[k].offset = step;
-        step += fields[k].size * fields[k].count;
-        if (fields[k].name == "x") ix = (int)k;
-        if (fields[k].name == "y") iy = (int)k;
-        if (fields[k].name == "z") iz = (int)k;
+        const PcdField &pf = fields[k];
+        SF_CHECK((pf.size == 1 || pf.size == 2 || pf.size == 4 || pf.size == 8) && pf.count >= 1 && pf.count <= 4096 && (pf.type == 'F' || pf.type == 'I' || pf.type == 'U'),
+                 SF_ERR_INVALID, "%s: bad SIZE / TYPE / COUNT of field %s", path.c_str(), pf.name.c_str());
+        fields[k].offset = (int)step;
+        step += (int64_t)pf.size * pf.count;
+        SF_CHECK(step <= (1 << 20), SF_ERR_INVALID, "%s: point step too large", path.c_str());
+        if (pf.name == "x") ix = (int)k;
+        if (pf.name == "y") iy = (int)k;
+        if (pf.name == "z") iz = (int)k;
     }
     SF_CHECK(ix >= 0 && iy >= 0 && iz >= 0, SF_ERR_INVALID, "%s: no x/y/z fields", path.c_str());
+    for (int k : {ix, iy, iz})
+        SF_CHECK(fields[(size_t)k].type == 'F' && (fields[(size_t)k].size == 4 || fields[(size_t)k].size == 8), SF_ERR_INVALID, "%s: x/y/z must be F4 or F8", path.c_str());
+    SF_CHECK(points == 0 || step <= PCD_MAX_BYTES / points, SF_ERR_INVALID, "%s: %lld points x %lld bytes is too large", path.c_str(), (long long)points, (long long)step);
     xyz.resize((size_t)points * 3);
     if (data_kind == "ascii") {
         for (int64_t i = 0; i < points; ++i) {
@@ -124,11 +157,11 @@ int pcd_read(const std::string &path, std::vector<float> &xyz)
     }
     std::vector<unsigned char> raw;
     if (data_kind == "binary") {
-        raw.resize((size_t)points * step);
+        raw.resize((size_t)points * (size_t)step);
         f.read(reinterpret_cast<char *>(raw.data()), (std::streamsize)raw.size());
         SF_CHECK((size_t)f.gcount() == raw.size(), SF_ERR_INVALID, "%s: truncated binary data", path.c_str());
         for (int64_t i = 0; i < points; ++i) {
-            const unsigned char *p = raw.data() + (size_t)i * step;
+            const unsigned char *p = raw.data() + (size_t)i * (size_t)step;
             xyz[3 * (size_t)i] = (float)read_scalar(p + fields[ix].offset, fields[ix]);
             xyz[3 * (size_t)i + 1] = (float)read_scalar(p + fields[iy].offset, fields[iy]);
             xyz[3 * (size_t)i + 2] = (float)read_scalar(p + fields[iz].offset, fields[iz]);
@@ -138,10 +171,15 @@ int pcd_read(const std::string &path, std::vector<float> &xyz)
     if (data_kind == "binary_compressed") { // LZF block, fields stored one after the other (SoA)
         uint32_t comp = 0, uncomp = 0;
         f.read(reinterpret_cast<char *>(&comp), 4);
+        SF_CHECK(f.gcount() == 4, SF_ERR_INVALID, "%s: truncated compressed header", path.c_str());
         f.read(reinterpret_cast<char *>(&uncomp), 4);
-        SF_CHECK((size_t)uncomp == (size_t)points * step, SF_ERR_INVALID, "%s: compressed size mismatch", path.c_str());
+        SF_CHECK(f.gcount() == 4, SF_ERR_INVALID, "%s: truncated compressed header", path.c_str());
+        SF_CHECK((size_t)uncomp == (size_t)points * (size_t)step, SF_ERR_INVALID, "%s: compressed size mismatch", path.c_str());
+        // LZF cannot expand: a stream longer than its output (+ control bytes) is not a PCD block
+        SF_CHECK((uint64_t)comp <= (uint64_t)uncomp + (uint64_t)uncomp / 16 + 64, SF_ERR_INVALID, "%s: compressed size %u is implausible", path.c_str(), comp);
         std::vector<unsigned char> cbuf(comp);
         f.read(reinterpret_cast<char *>(cbuf.data()), comp);
+        SF_CHECK((uint32_t)f.gcount() == comp, SF_ERR_INVALID, "%s: truncated compressed data", path.c_str());
         raw.resize(uncomp);
         SF_CHECK(lzf_decompress(cbuf.data(), comp, raw.data(), uncomp) == uncomp, SF_ERR_INVALID, "%s: LZF stream corrupt", path.c_str());
         size_t base = 0;
@@ -175,13 +213,15 @@ int pcd_write_binary(const std::string &path, const float *xyz, int64_t n)
 extern "C" int sf_pcd_read(const char *path, float **xyz, int64_t *n)
 {
     SF_CHECK(path && xyz && n, SF_ERR_INVALID, "bad arguments");
-    std::vector<float> v;
-    SF_TRY(pcd_read(path, v));
-    *n = (int64_t)(v.size() / 3);
-    *xyz = (float *)std::malloc(sizeof(float) * std::max<size_t>(v.size(), 1));
-    SF_CHECK(*xyz, SF_ERR_NOMEM, "out of host memory");
-    std::memcpy(*xyz, v.data(), sizeof(float) * v.size());
-    return SF_OK;
+    return guarded([&]() -> int {
+        std::vector<float> v;
+        SF_TRY(pcd_read(path, v));
+        *n = (int64_t)(v.size() / 3);
+        *xyz = (float *)std::malloc(sizeof(float) * std::max<size_t>(v.size(), 1));
+        SF_CHECK(*xyz, SF_ERR_NOMEM, "out of host memory");
+        std::memcpy(*xyz, v.data(), sizeof(float) * v.size());
+        return SF_OK;
+    });
 }
 
 extern "C" void sf_free(void *p) { std::free(p); }
@@ -189,23 +229,27 @@ extern "C" void sf_free(void *p) { std::free(p); }
 extern "C" int sf_pcd_write_binary(const char *path, const float *xyz, int64_t n)
 {
     SF_CHECK(path && n >= 0 && (xyz || n == 0), SF_ERR_INVALID, "bad arguments");
-    return pcd_write_binary(path, xyz, n);
+    return guarded([&]() -> int { return pcd_write_binary(path, xyz, n); });
 }
 
 extern "C" int sf_cloud_load_pcd(sf_cloud *c, const char *path)
 {
     SF_CHECK(c && path, SF_ERR_INVALID, "bad arguments");
-    std::vector<float> v;
-    SF_TRY(pcd_read(path, v));
-    return sf_cloud_upload(c, v.data(), (int64_t)(v.size() / 3));
+    return guarded([&]() -> int {
+        std::vector<float> v;
+        SF_TRY(pcd_read(path, v));
+        return sf_cloud_upload(c, v.data(), (int64_t)(v.size() / 3));
+    });
 }
 
 extern "C" int sf_cloud_save_pcd(sf_cloud *c, const char *path)
 {
     SF_CHECK(c && path, SF_ERR_INVALID, "bad arguments");
-    std::vector<float> v((size_t)c->n * 3);
-    SF_TRY(sf_cloud_download(c, v.data(), c->n, nullptr));
-    return pcd_write_binary(path, v.data(), c->n);
+    return guarded([&]() -> int {
+        std::vector<float> v((size_t)c->n * 3);
+        SF_TRY(sf_cloud_download(c, v.data(), c->n, nullptr));
+        return pcd_write_binary(path, v.data(), c->n);
+    });
 }
 
 // ------------------------------------------------------------------ GlobalMapFramesManager
@@ -274,6 +318,7 @@ extern "C" void sf_frames_destroy(sf_frames *fr) { delete fr; }
 extern "C" int sf_frames_get_map_cloud(sf_frames *fr, sf_cloud *out, float voxel_size, int *loaded_cached)
 {
     SF_CHECK(fr && out, SF_ERR_INVALID, "bad arguments");
+    return guarded([&]() -> int {
     const std::string cached = fr->data_folder + "/" + fr->map_name + ".pcd";
     if (access(cached.c_str(), F_OK) != -1) { // cached map: loaded as is, NO voxel grid on this branch
         if (loaded_cached) *loaded_cached = 1;
@@ -296,12 +341,14 @@ extern "C" int sf_frames_get_map_cloud(sf_frames *fr, sf_cloud *out, float voxel
     int flags = 0;
     SF_TRY(sf_cloud_voxel_downsample(out, voxel_size, SF_VOXEL_PCL, &flags));
     return sf_cloud_save_pcd(out, cached.c_str());
+    });
 }
 
 // getMapTGlobal (:182-248): parse, filterBadReadings (:153-180), truncate, computeMapTGlobal
 extern "C" int sf_frames_get_map_T_global(sf_frames *fr, double T[16])
 {
     SF_CHECK(fr && T, SF_ERR_INVALID, "bad arguments");
+    return guarded([&]() -> int {
     std::vector<double> odom = load_odometry_positions(fr->data_folder + "/odometry_positions.txt");
     std::vector<double> lla;
     std::vector<float> yaw;
@@ -333,6 +380,7 @@ extern "C" int sf_frames_get_map_T_global(sf_frames *fr, double T[16])
     }
     sf_fusion_map_T_global(lla.data(), yaw.data(), (int)compute_size, T);
     return SF_OK;
+    });
 }
 
 extern "C" float sf_frames_get_closest_altitude(sf_frames *fr, double lat, double lon)
@@ -351,4 +399,109 @@ extern "C" int sf_frames_altitude_table(sf_frames *fr, double *table, int64_t ca
         std::memcpy(table, fr->altitude_table.data(), sizeof(double) * fr->altitude_table.size());
     }
     return SF_OK;
+}
+
+// ------------------------------------------------------------------ recorder-side writers (MapDataSaver)
+// mapping/src/map_data_save_node.cpp:12-29 (folder wiped and re-created, the two text logs with their
+// header lines), :61-98 (per synchronized triple: the cloud is appended to the open tile; every
+// cloud_save_rate_ = 10 clouds (map_data_save_node.h:72) the tile is written as cloud_<counter>.pcd
+// with pcl::io::savePCDFileBinary and cleared; one "tx ty tz" line with default ostream formatting;
+// one "lat lon alt y" line with std::fixed << std::setprecision(8)), :100-112 (the open tile is
+// flushed on shutdown).  Host code: it is file I/O around the path, not arithmetic on it.
+struct sf_recorder {
+    std::string folder;
+    std::vector<float> tile;
+    int cloud_counter = 0;
+    int save_rate = 10;
+};
+
+namespace {
+int recorder_flush(sf_recorder *r)
+{
+    const std::string path = r->folder + "/cloud_" + std::to_string(r->cloud_counter) + ".pcd";
+    SF_TRY(pcd_write_binary(path, r->tile.data(), (int64_t)(r->tile.size() / 3)));
+    r->tile.clear();
+    return SF_OK;
+}
+
+int remove_tree(const std::string &path)
+{
+    DIR *dir = opendir(path.c_str());
+    if (!dir) return errno == ENOENT ? 0 : -1;
+    int rc = 0;
+    while (struct dirent *ent = readdir(dir)) {
+        const std::string n = ent->d_name;
+        if (n == "." || n == "..") continue;
+        const std::string child = path + "/" + n;
+        struct stat st;
+        if (lstat(child.c_str(), &st) != 0) { rc = -1; continue; }
+        if (S_ISDIR(st.st_mode)) rc |= remove_tree(child);
+        else if (unlink(child.c_str()) != 0) rc = -1;
+    }
+    closedir(dir);
+    if (rmdir(path.c_str()) != 0) rc = -1;
+    return rc;
+}
+} // namespace
+
+extern "C" int sf_recorder_create(const char *map_data_path, sf_recorder **out)
+{
+    SF_CHECK(map_data_path && out && map_data_path[0], SF_ERR_INVALID, "bad arguments");
+    return guarded([&]() -> int {
+        const std::string folder = map_data_path;
+        struct stat st;
+        if (stat(folder.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) // :16-20 (the reference shells out to rm -rf)
+            SF_CHECK(remove_tree(folder) == 0, SF_ERR_INVALID, "cannot clear %s", folder.c_str());
+        SF_CHECK(mkdir(folder.c_str(), 0755) == 0 || errno == EEXIST, SF_ERR_INVALID, "cannot create %s", folder.c_str());
+        {
+            std::ofstream f(folder + "/odometry_positions.txt");
+            SF_CHECK(f.is_open(), SF_ERR_INVALID, "cannot create the odometry log in %s", folder.c_str());
+            f << "tx ty tz\n";
+        }
+        {
+            std::ofstream f(folder + "/gps_imu_poses.txt");
+            SF_CHECK(f.is_open(), SF_ERR_INVALID, "cannot create the GPS log in %s", folder.c_str());
+            f << "lat lon alt y\n";
+        }
+        sf_recorder *r = new sf_recorder();
+        r->folder = folder;
+        *out = r;
+        return SF_OK;
+    });
+}
+
+extern "C" int sf_recorder_add(sf_recorder *r, const float *xyz, int64_t n, const double odom_xyz[3], double lat, double lon, double alt, double compass_yaw)
+{
+    SF_CHECK(r && n >= 0 && (xyz || n == 0) && odom_xyz, SF_ERR_INVALID, "bad arguments");
+    return guarded([&]() -> int {
+        r->tile.insert(r->tile.end(), xyz, xyz + 3 * (size_t)n);
+        ++r->cloud_counter;
+        if (r->cloud_counter % r->save_rate == 0) SF_TRY(recorder_flush(r));
+        std::ofstream fo(r->folder + "/odometry_positions.txt", std::ios::app);
+        fo << odom_xyz[0] << " " << odom_xyz[1] << " " << odom_xyz[2] << std::endl;
+        std::ofstream fg(r->folder + "/gps_imu_poses.txt", std::ios::app);
+        fg << std::fixed << std::setprecision(8) << lat << " " << lon << " " << alt << " " << compass_yaw << std::endl;
+        SF_CHECK(fo.good() && fg.good(), SF_ERR_INVALID, "write to the logs in %s failed", r->folder.c_str());
+        return SF_OK;
+    });
+}
+
+extern "C" int sf_recorder_shutdown(sf_recorder *r)
+{
+    SF_CHECK(r, SF_ERR_INVALID, "bad arguments");
+    return guarded([&]() -> int {
+        if (!r->tile.empty()) SF_TRY(recorder_flush(r));
+        return SF_OK;
+    });
+}
+
+extern "C" void sf_recorder_destroy(sf_recorder *r) { delete r; }
+
+// map_data_save_node.cpp:38-49 (double arithmetic; the localization node's float twin is sf_fusion_compass_to_yaw)
+extern "C" double sf_recorder_compass_yaw(double compass_hdg_deg)
+{
+    double yaw = (90.0 - compass_hdg_deg) * M_PI / 180.0;
+    if (yaw > M_PI) yaw -= 2 * M_PI;
+    else if (yaw < -M_PI) yaw += 2 * M_PI;
+    return yaw;
 }

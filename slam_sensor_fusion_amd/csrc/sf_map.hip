@@ -98,7 +98,7 @@ extern "C" void sf_map_destroy(sf_map *m)
     if (!m) return;
     hipError_t e = hipStreamSynchronize(m->ctx->stream);
     (void)e;
-    m->pts4.release(); m->nrm4.release(); m->cell_start.release(); m->keys.release(); m->vals.release();
+    m->pts4.release(); m->nrm4.release(); m->cov6.release(); m->cell_start.release(); m->keys.release(); m->vals.release();
     m->keys2.release(); m->vals2.release(); m->inv_perm.release();
     sf_ctx *ctx = m->ctx;
     delete m;
@@ -199,6 +199,8 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
     G.nrm = nullptr;
     G.n = n_valid;
     m->built = true;
+    m->has_cov = false;
+    m->generation = sf::next_generation();
     return SF_OK;
 }
 
@@ -293,7 +295,6 @@ extern "C" int sf_map_nn(sf_map *m, const float *queries, int64_t n, float max_d
     SF_HIP(hipMemcpyAsync(idx, di.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipMemcpyAsync(d2, dd.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
-    dq.release(); di.release(); dd.release();
     return SF_OK;
 }
 
@@ -346,7 +347,7 @@ __device__ void smallest_eigvec(const double C[9], double nrm[3])
     nrm[0] = x; nrm[1] = y; nrm[2] = z;
 }
 
-__global__ __launch_bounds__(256) void k_normals(SfGrid g, double r2, int R, float4 *__restrict__ nrm4)
+__global__ __launch_bounds__(256) void k_normals(SfGrid g, double r2, int R, float4 *__restrict__ nrm4, double *__restrict__ cov6)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= g.n) return;
@@ -387,6 +388,10 @@ __global__ __launch_bounds__(256) void k_normals(SfGrid g, double r2, int R, flo
         smallest_eigvec(M, nv);
     }
     nrm4[j] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], __int_as_float(cnt));
+    if (cov6) { // xx xy xz yy yz zz of the centred neighbourhood, divided by the neighbour count (zeros below 3 neighbours)
+#pragma unroll
+        for (int d = 0; d < 6; ++d) cov6[6 * (size_t)j + d] = cnt >= 3 ? C[d] / (double)cnt : 0.0;
+    }
 }
 
 __global__ void k_normals_from_host_order(SfGrid g, const float *__restrict__ nrm_orig, float4 *__restrict__ nrm4)
@@ -395,6 +400,15 @@ __global__ void k_normals_from_host_order(SfGrid g, const float *__restrict__ nr
     if (j >= g.n) return;
     const uint32_t i = __float_as_uint(g.pts[j].w);
     nrm4[j] = make_float4(nrm_orig[3 * (size_t)i], nrm_orig[3 * (size_t)i + 1], nrm_orig[3 * (size_t)i + 2], __int_as_float(0));
+}
+
+__global__ void k_cov_to_host_order(SfGrid g, const double *__restrict__ cov6, double *__restrict__ cov_orig)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= g.n) return;
+    const uint32_t i = __float_as_uint(g.pts[j].w);
+#pragma unroll
+    for (int d = 0; d < 6; ++d) cov_orig[6 * (size_t)i + d] = cov6[6 * (size_t)j + d];
 }
 
 __global__ void k_normals_to_host_order(SfGrid g, const float4 *__restrict__ nrm4, float *__restrict__ nrm_orig, int32_t *__restrict__ cnt_orig)
@@ -409,20 +423,45 @@ __global__ void k_normals_to_host_order(SfGrid g, const float4 *__restrict__ nrm
 
 } // namespace
 
-extern "C" int sf_map_estimate_normals(sf_map *m, float radius)
+extern "C" int sf_map_estimate_normals_cov(sf_map *m, float radius, int with_covariance)
 {
     SF_CHECK(m && m->built, SF_ERR_STATE, "map not built");
     SF_CHECK(radius > 0, SF_ERR_INVALID, "radius must be positive");
     sf_ctx *ctx = m->ctx;
     SF_HIP(hipSetDevice(ctx->device));
     SF_TRY(m->nrm4.reserve(sizeof(float4) * (size_t)std::max<int64_t>(m->n, 1)));
+    m->has_cov = false;
+    if (with_covariance) SF_TRY(m->cov6.reserve(sizeof(double) * 6 * (size_t)std::max<int64_t>(m->n, 1)));
     const int R = std::max(1, (int)std::ceil((double)radius / (double)m->grid.h - 1e-9));
     if (m->grid.n > 0)
-        hipLaunchKernelGGL(k_normals, dim3(nblk(m->grid.n)), dim3(256), 0, ctx->stream, m->grid, (double)radius * (double)radius, R, m->nrm4.as<float4>());
+        hipLaunchKernelGGL(k_normals, dim3(nblk(m->grid.n)), dim3(256), 0, ctx->stream, m->grid, (double)radius * (double)radius, R, m->nrm4.as<float4>(),
+                           with_covariance ? m->cov6.as<double>() : nullptr);
     SF_HIP(hipGetLastError());
     SF_HIP(hipStreamSynchronize(ctx->stream));
     m->grid.nrm = m->nrm4.as<float4>();
     m->has_normals = true;
+    m->has_cov = with_covariance != 0;
+    m->generation = sf::next_generation();
+    return SF_OK;
+}
+
+extern "C" int sf_map_estimate_normals(sf_map *m, float radius) { return sf_map_estimate_normals_cov(m, radius, 0); }
+
+extern "C" int sf_map_download_covariances(sf_map *m, double *cov6, int64_t cap, int64_t *n)
+{
+    SF_CHECK(m && m->built && m->has_cov, SF_ERR_STATE, "no covariances (sf_map_estimate_normals_cov with with_covariance = 1)");
+    if (n) *n = m->n;
+    SF_CHECK(cap >= m->n && cov6, SF_ERR_INVALID, "buffer too small");
+    sf_ctx *ctx = m->ctx;
+    SF_HIP(hipSetDevice(ctx->device));
+    sf::DevBuf dc;
+    const size_t bytes = sizeof(double) * 6 * (size_t)std::max<int64_t>(m->n, 1);
+    SF_TRY(dc.reserve(bytes));
+    SF_HIP(hipMemsetAsync(dc.p, 0, bytes, ctx->stream)); // points that are not indexed (non-finite) keep zeros
+    if (m->grid.n > 0)
+        hipLaunchKernelGGL(k_cov_to_host_order, dim3(nblk(m->grid.n)), dim3(256), 0, ctx->stream, m->grid, m->cov6.as<double>(), dc.as<double>());
+    SF_HIP(hipMemcpyAsync(cov6, dc.p, sizeof(double) * 6 * (size_t)m->n, hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
     return SF_OK;
 }
 
@@ -439,9 +478,10 @@ extern "C" int sf_map_set_normals(sf_map *m, const float *normals, int64_t n)
     if (m->grid.n > 0)
         hipLaunchKernelGGL(k_normals_from_host_order, dim3(nblk(m->grid.n)), dim3(256), 0, ctx->stream, m->grid, tmp.as<float>(), m->nrm4.as<float4>());
     SF_HIP(hipStreamSynchronize(ctx->stream));
-    tmp.release();
     m->grid.nrm = m->nrm4.as<float4>();
     m->has_normals = true;
+    m->has_cov = false;
+    m->generation = sf::next_generation();
     return SF_OK;
 }
 
@@ -462,6 +502,5 @@ extern "C" int sf_map_download_normals(sf_map *m, float *normals, int32_t *n_nei
     SF_HIP(hipMemcpyAsync(normals, dn.p, sizeof(float) * 3 * (size_t)m->n, hipMemcpyDeviceToHost, ctx->stream));
     if (n_neighbors) SF_HIP(hipMemcpyAsync(n_neighbors, dc.p, sizeof(int32_t) * (size_t)m->n, hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
-    dn.release(); dc.release();
     return SF_OK;
 }

@@ -21,22 +21,25 @@ namespace {
 
 inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)sf::div_up(n > 0 ? n : 1, b); }
 
-struct PclGeom { float inv; int min_b[3]; int mul[3]; };
+struct PclGeom { float inv; int min_b[3]; int64_t mul[3]; };
 
-__global__ void k_pcl_keys(const float *__restrict__ xyz, int64_t n, PclGeom g, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, int32_t *__restrict__ point_ids)
+// K = uint32_t / ID = int32_t: pcl::VoxelGrid's int32 linear index (SF_VOXEL_PCL);
+// K = uint64_t / ID = int64_t: the same arithmetic with the index kept in 64 bits (SF_VOXEL_PCL64)
+template <class K, class ID>
+__global__ void k_pcl_keys(const float *__restrict__ xyz, int64_t n, PclGeom g, K *__restrict__ keys, uint32_t *__restrict__ vals, ID *__restrict__ point_ids)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    uint32_t key = 0xffffffffu;
-    int32_t id = -1;
+    K key = ~(K)0;
+    ID id = -1;
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
         // voxel_grid.hpp: static_cast<int>(std::floor(p.x * inverse_leaf_size_[0]) - static_cast<float>(min_b_[0]))
         const int i0 = (int)(floorf(__fmul_rn(x, g.inv)) - (float)g.min_b[0]);
         const int i1 = (int)(floorf(__fmul_rn(y, g.inv)) - (float)g.min_b[1]);
         const int i2 = (int)(floorf(__fmul_rn(z, g.inv)) - (float)g.min_b[2]);
-        id = i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2];
-        key = (uint32_t)id;
+        id = (ID)((ID)i0 * (ID)g.mul[0] + (ID)i1 * (ID)g.mul[1] + (ID)i2 * (ID)g.mul[2]);
+        key = (K)id;
     }
     keys[i] = key;
     vals[i] = (uint32_t)i;
@@ -67,12 +70,13 @@ __global__ void k_heads(const K *__restrict__ keys, int64_t n_valid, uint32_t *_
 }
 
 // one lane per voxel: float32 sums in ascending point id (pcl::CentroidPoint / AccumulatorXYZ)
-__global__ void k_pcl_centroids(const float *__restrict__ xyz, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ flags,
-                                const uint32_t *__restrict__ pos, int64_t n_valid, float *__restrict__ out, int32_t *__restrict__ out_ids)
+template <class K, class ID>
+__global__ void k_pcl_centroids(const float *__restrict__ xyz, const K *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ flags,
+                                const uint32_t *__restrict__ pos, int64_t n_valid, float *__restrict__ out, ID *__restrict__ out_ids)
 {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_valid || !flags[j]) return;
-    const uint32_t key = keys[j];
+    const K key = keys[j];
     float sx = 0.f, sy = 0.f, sz = 0.f;
     int cnt = 0;
     for (int64_t k = j; k < n_valid && keys[k] == key; ++k) {
@@ -85,7 +89,7 @@ __global__ void k_pcl_centroids(const float *__restrict__ xyz, const uint32_t *_
     const float c = (float)cnt;
     const size_t o = pos[j];
     out[3 * o] = __fdiv_rn(sx, c); out[3 * o + 1] = __fdiv_rn(sy, c); out[3 * o + 2] = __fdiv_rn(sz, c);
-    out_ids[o] = (int32_t)key;
+    out_ids[o] = (ID)key;
 }
 
 // float64 means in ascending point id (open3d AccumulatedPoint)
@@ -132,8 +136,10 @@ int scan_heads(sf_ctx *ctx, const K *keys, int64_t n_valid, uint32_t *flags, uin
     return SF_OK;
 }
 
+template <class K, class ID>
 int voxel_pcl(sf_cloud *c, float leaf, int *status_flags)
 {
+    constexpr bool WIDE = sizeof(K) == 8;
     sf_ctx *ctx = c->ctx;
     hipStream_t st = ctx->stream;
     const int64_t n = c->n;
@@ -145,53 +151,51 @@ int voxel_pcl(sf_cloud *c, float leaf, int *status_flags)
     const int64_t dx = (int64_t)((mm.mx[0] - mm.mn[0]) * inv) + 1;
     const int64_t dy = (int64_t)((mm.mx[1] - mm.mn[1]) * inv) + 1;
     const int64_t dz = (int64_t)((mm.mx[2] - mm.mn[2]) * inv) + 1;
-    if (dx * dy * dz > (int64_t)INT32_MAX) {
+    if (!WIDE && dx * dy * dz > (int64_t)INT32_MAX) {
         if (status_flags) *status_flags |= SF_FLAG_VOXEL_OVERFLOW;
         return SF_OK; // "Leaf size is too small ... Integer indices would overflow": output = input
     }
     PclGeom g;
     g.inv = inv;
-    int div_b[3];
+    int64_t div_b[3];
     for (int d = 0; d < 3; ++d) {
         g.min_b[d] = (int)std::floor(mm.mn[d] * inv);
         const int max_b = (int)std::floor(mm.mx[d] * inv);
-        div_b[d] = max_b - g.min_b[d] + 1;
+        div_b[d] = (int64_t)max_b - (int64_t)g.min_b[d] + 1;
     }
     g.mul[0] = 1; g.mul[1] = div_b[0]; g.mul[2] = div_b[0] * div_b[1];
+    if (WIDE) SF_CHECK((double)div_b[0] * (double)div_b[1] * (double)div_b[2] < 9.0e18, SF_ERR_OVERFLOW, "voxel index does not fit 63 bits");
 
-    sf::DevBuf keys, keys2, vals, vals2, flags, pos, out;
-    int rc = SF_OK;
-    auto cleanup = [&]() { keys.release(); keys2.release(); vals.release(); vals2.release(); flags.release(); pos.release(); };
-#define VX_TRY(e) do { rc = (e); if (rc != SF_OK) { cleanup(); out.release(); return rc; } } while (0)
-    VX_TRY(keys.reserve(sizeof(uint32_t) * (size_t)n));
-    VX_TRY(keys2.reserve(sizeof(uint32_t) * (size_t)n));
-    VX_TRY(vals.reserve(sizeof(uint32_t) * (size_t)n));
-    VX_TRY(vals2.reserve(sizeof(uint32_t) * (size_t)n));
-    VX_TRY(flags.reserve(sizeof(uint32_t) * (size_t)n));
-    VX_TRY(pos.reserve(sizeof(uint32_t) * (size_t)n));
-    VX_TRY(c->vox_point_ids.reserve(sizeof(int32_t) * (size_t)n));
-    hipLaunchKernelGGL(k_pcl_keys, dim3(nblk(n)), dim3(256), 0, st, c->xyz.as<float>(), n, g, keys.as<uint32_t>(), vals.as<uint32_t>(), c->vox_point_ids.as<int32_t>());
+    sf::DevBuf keys, keys2, vals, vals2, flags, pos;
+    sf::DevBuf &out = c->spare;
+    SF_TRY(keys.reserve(sizeof(K) * (size_t)n));
+    SF_TRY(keys2.reserve(sizeof(K) * (size_t)n));
+    SF_TRY(vals.reserve(sizeof(uint32_t) * (size_t)n));
+    SF_TRY(vals2.reserve(sizeof(uint32_t) * (size_t)n));
+    SF_TRY(flags.reserve(sizeof(uint32_t) * (size_t)n));
+    SF_TRY(pos.reserve(sizeof(uint32_t) * (size_t)n));
+    SF_TRY(c->vox_point_ids.reserve(sizeof(ID) * (size_t)n));
+    hipLaunchKernelGGL((k_pcl_keys<K, ID>), dim3(nblk(n)), dim3(256), 0, st, c->xyz.as<float>(), n, g, keys.as<K>(), vals.as<uint32_t>(), c->vox_point_ids.as<ID>());
     size_t tmp = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, keys.as<uint32_t>(), keys2.as<uint32_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), (size_t)n, 0, 32, st);
-    if (e != hipSuccess) { sf::set_error("radix_sort_pairs(size): %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
-    VX_TRY(sf::ensure_scratch(ctx, tmp));
-    e = rocprim::radix_sort_pairs(ctx->scratch.p, tmp, keys.as<uint32_t>(), keys2.as<uint32_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), (size_t)n, 0, 32, st);
-    if (e != hipSuccess) { sf::set_error("radix_sort_pairs: %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
+    const unsigned end_bit = 8 * sizeof(K); // every bit: non-finite points carry the all-ones key and must sort last
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, keys.as<K>(), keys2.as<K>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), (size_t)n, 0, end_bit, st);
+    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs(size): %s", hipGetErrorString(e));
+    SF_TRY(sf::ensure_scratch(ctx, tmp));
+    e = rocprim::radix_sort_pairs(ctx->scratch.p, tmp, keys.as<K>(), keys2.as<K>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), (size_t)n, 0, end_bit, st);
+    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs: %s", hipGetErrorString(e));
     int64_t n_vox = 0;
-    VX_TRY(scan_heads<uint32_t>(ctx, keys2.as<uint32_t>(), mm.n_finite, flags.as<uint32_t>(), pos.as<uint32_t>(), &n_vox));
-    VX_TRY(out.reserve(sizeof(float) * 3 * (size_t)n_vox));
-    VX_TRY(c->vox_out_ids.reserve(sizeof(int32_t) * (size_t)n_vox));
-    hipLaunchKernelGGL(k_pcl_centroids, dim3(nblk(mm.n_finite)), dim3(256), 0, st, c->xyz.as<float>(), keys2.as<uint32_t>(), vals2.as<uint32_t>(), flags.as<uint32_t>(),
-                       pos.as<uint32_t>(), mm.n_finite, out.as<float>(), c->vox_out_ids.as<int32_t>());
-    e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { sf::set_error("voxel kernels: %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
-#undef VX_TRY
-    cleanup();
-    c->xyz.release();
-    c->xyz = out;
+    SF_TRY(scan_heads<K>(ctx, keys2.as<K>(), mm.n_finite, flags.as<uint32_t>(), pos.as<uint32_t>(), &n_vox));
+    SF_TRY(out.reserve(sizeof(float) * 3 * (size_t)n_vox));
+    SF_TRY(c->vox_out_ids.reserve(sizeof(ID) * (size_t)n_vox));
+    hipLaunchKernelGGL((k_pcl_centroids<K, ID>), dim3(nblk(mm.n_finite)), dim3(256), 0, st, c->xyz.as<float>(), keys2.as<K>(), vals2.as<uint32_t>(), flags.as<uint32_t>(),
+                       pos.as<uint32_t>(), mm.n_finite, out.as<float>(), c->vox_out_ids.as<ID>());
+    e = hipStreamSynchronize(st); // the temporaries above are freed on return
+    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "voxel kernels: %s", hipGetErrorString(e));
+    c->xyz.swap(out);
     c->n_vox_point_vals = n;
     c->n_vox_out_vals = n_vox;
     c->n_vox_out_pts = 0;
+    c->vox_wide = WIDE;
     c->n = n_vox;
     c->n_last_idx = -1;
     return SF_OK;
@@ -216,10 +220,9 @@ int voxel_o3d(sf_cloud *c, double voxel)
     SF_CHECK(!(voxel * (double)INT_MAX < span), SF_ERR_OVERFLOW, "voxel_size is too small.");
     SF_CHECK(span / voxel + 2 < 2097152.0, SF_ERR_OVERFLOW, "more than 2^21 voxels along one axis");
 
-    sf::DevBuf keys, keys2, vals, vals2, flags, pos, out;
-    int rc = SF_OK;
-    auto cleanup = [&]() { keys.release(); keys2.release(); vals.release(); vals2.release(); flags.release(); pos.release(); };
-#define VX_TRY(e) do { rc = (e); if (rc != SF_OK) { cleanup(); out.release(); return rc; } } while (0)
+    sf::DevBuf keys, keys2, vals, vals2, flags, pos; // freed on return (every path)
+    sf::DevBuf &out = c->spare;
+#define VX_TRY(e) SF_TRY(e)
     VX_TRY(keys.reserve(sizeof(uint64_t) * (size_t)n));
     VX_TRY(keys2.reserve(sizeof(uint64_t) * (size_t)n));
     VX_TRY(vals.reserve(sizeof(uint32_t) * (size_t)n));
@@ -244,9 +247,8 @@ int voxel_o3d(sf_cloud *c, double voxel)
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) { sf::set_error("voxel kernels: %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
 #undef VX_TRY
-    cleanup();
-    c->xyz.release();
-    c->xyz = out;
+    c->xyz.swap(out);
+    c->vox_wide = false;
     c->n_vox_point_vals = 3 * n;
     c->n_vox_out_vals = 3 * n_vox;
     c->n_vox_out_pts = n_vox;
@@ -271,24 +273,55 @@ int download_i32(sf_cloud *c, const sf::DevBuf &buf, int64_t have, int32_t *dst,
 extern "C" int sf_cloud_voxel_downsample(sf_cloud *c, double leaf, int flavour, int *status_flags)
 {
     SF_CHECK(c && leaf > 0, SF_ERR_INVALID, "bad arguments");
-    SF_CHECK(flavour == SF_VOXEL_PCL || flavour == SF_VOXEL_O3D, SF_ERR_INVALID, "unknown voxel flavour %d", flavour);
+    SF_CHECK(flavour == SF_VOXEL_PCL || flavour == SF_VOXEL_O3D || flavour == SF_VOXEL_PCL64, SF_ERR_INVALID, "unknown voxel flavour %d", flavour);
     SF_HIP(hipSetDevice(c->ctx->device));
     if (status_flags) *status_flags = 0;
     c->n_vox_point_vals = c->n_vox_out_vals = c->n_vox_out_pts = 0;
     if (c->n == 0) return SF_OK;
-    return flavour == SF_VOXEL_PCL ? voxel_pcl(c, (float)leaf, status_flags) : voxel_o3d(c, leaf);
+    if (flavour == SF_VOXEL_PCL) return voxel_pcl<uint32_t, int32_t>(c, (float)leaf, status_flags);
+    if (flavour == SF_VOXEL_PCL64) return voxel_pcl<uint64_t, int64_t>(c, (float)leaf, status_flags);
+    return voxel_o3d(c, leaf);
 }
 
 extern "C" int sf_cloud_voxel_point_ids(sf_cloud *c, int32_t *ids, int64_t cap_values, int64_t *n_values)
 {
     SF_CHECK(c, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(!c->vox_wide, SF_ERR_STATE, "the last downsample used 64-bit indices: sf_cloud_voxel_point_ids64");
     return download_i32(c, c->vox_point_ids, c->n_vox_point_vals, ids, cap_values, n_values);
 }
 
 extern "C" int sf_cloud_voxel_out_ids(sf_cloud *c, int32_t *ids, int64_t cap_values, int64_t *n_values)
 {
     SF_CHECK(c, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(!c->vox_wide, SF_ERR_STATE, "the last downsample used 64-bit indices: sf_cloud_voxel_out_ids64");
     return download_i32(c, c->vox_out_ids, c->n_vox_out_vals, ids, cap_values, n_values);
+}
+
+namespace {
+int download_i64(sf_cloud *c, const sf::DevBuf &buf, int64_t have, int64_t *dst, int64_t cap, int64_t *n)
+{
+    if (n) *n = have;
+    SF_CHECK(cap >= have && (dst || have == 0), SF_ERR_INVALID, "buffer too small: %lld < %lld", (long long)cap, (long long)have);
+    if (have > 0) {
+        SF_HIP(hipMemcpyAsync(dst, buf.p, sizeof(int64_t) * (size_t)have, hipMemcpyDeviceToHost, c->ctx->stream));
+        SF_HIP(hipStreamSynchronize(c->ctx->stream));
+    }
+    return SF_OK;
+}
+} // namespace
+
+extern "C" int sf_cloud_voxel_point_ids64(sf_cloud *c, int64_t *ids, int64_t cap_values, int64_t *n_values)
+{
+    SF_CHECK(c, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(c->vox_wide || c->n_vox_point_vals == 0, SF_ERR_STATE, "the last downsample used 32-bit indices");
+    return download_i64(c, c->vox_point_ids, c->n_vox_point_vals, ids, cap_values, n_values);
+}
+
+extern "C" int sf_cloud_voxel_out_ids64(sf_cloud *c, int64_t *ids, int64_t cap_values, int64_t *n_values)
+{
+    SF_CHECK(c, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(c->vox_wide || c->n_vox_out_vals == 0, SF_ERR_STATE, "the last downsample used 32-bit indices");
+    return download_i64(c, c->vox_out_ids, c->n_vox_out_vals, ids, cap_values, n_values);
 }
 
 extern "C" int sf_cloud_voxel_out_means_f64(sf_cloud *c, double *xyz, int64_t cap_points, int64_t *n_points)

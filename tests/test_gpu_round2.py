@@ -1,0 +1,172 @@
+"""GPU parity tests added in round 2: the hipGraph cache key, the int64-index voxel
+grid (SF_VOXEL_PCL64), the covariance export of the normal estimation (SURVEY x2 "+6 cov"), the
+checked PointCloud2 entry point.  All through the C ABI, against the oracle."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_graph_replay_follows_parameters_and_map_rebuilds(api, ctx, synth, small_world):
+    """A captured launch list bakes thresholds, IcpParams and the SfGrid (by value) into its kernel
+    arguments.  With hipGraph replay on, changing a parameter through the setters or rebuilding the
+    SAME sf_map handle in place (map growth: the allocation usually survives, its content does not)
+    must re-capture: every alignment equals the graph-off run bit for bit."""
+    m = small_world["map"]
+    scans = np.stack([synth.make_scan(m, 4000, scan_id=s)[0] for s in range(2)])
+    cloud = api.Cloud(ctx, m[: len(m) - 3000])
+    mp = api.Map(ctx, cloud, 0.25)
+    mp.estimate_normals(0.25)
+    ref_map = api.Map(ctx, api.Cloud(ctx, m[: len(m) - 3000]), 0.25)
+    ref_map.estimate_normals(0.25)
+
+    def pair():
+        out = []
+        for graph, target in ((True, mp), (False, ref_map)):
+            icp = api.Icp(ctx, 5.0, 12, 0.4, 1e-2)
+            icp.set_target(target)
+            icp.use_graph(graph)
+            icp.set_source_batch(scans)
+            out.append(icp)
+        return out
+
+    g, p = pair()
+
+    def same(mode):
+        a, b = g.align_batch(mode), p.align_batch(mode)
+        for x, y in zip(a, b):
+            assert np.array_equal(x["T64"], y["T64"]) and x["iterations"] == y["iterations"] and x["n_corr"] == y["n_corr"] and x["error"] == y["error"], mode
+
+    for mode in ("ref_cpp", "o3d_p2p", "p2plane"):
+        same(mode)                                       # capture at the coarse parameters (localization_node.cpp:226-229)
+        for icp in (g, p):                               # coarse -> fine switch, :24-28
+            icp.set_max_correspondence_dist(0.5)
+            icp.set_transformation_epsilon(1e-5)
+            icp.set_acceptable_mean_error(0.05)
+        same(mode)
+        same(mode)                                       # and a plain replay
+        for icp in (g, p):
+            icp.set_max_correspondence_dist(5.0)
+            icp.set_transformation_epsilon(1e-2)
+            icp.set_acceptable_mean_error(0.4)
+    # rebuild the same Map handle with a slightly larger cloud (sf_cloud_append use case): pointer may survive
+    bigger = api.Cloud(ctx, m)
+    mp.build(bigger, 0.25)
+    mp.estimate_normals(0.25)
+    ref_map = api.Map(ctx, api.Cloud(ctx, m), 0.25)
+    ref_map.estimate_normals(0.25)
+    p.set_target(ref_map)
+    for mode in ("p2plane", "o3d_p2p", "ref_cpp"):
+        same(mode)
+    mp.estimate_normals(0.4)                             # new normals in the same buffer
+    ref_map.estimate_normals(0.4)
+    same("p2plane")
+
+
+def test_voxel_pcl64_bit_exact_and_past_int32(api, ctx, orc, small_world):
+    raw = small_world["raw"].copy()
+    raw[11] = [np.nan, 0, 0]
+    c = api.Cloud(ctx, raw)
+    assert c.voxel_downsample(0.1, "pcl64") == 0
+    ds, vidx, ovox = orc.voxel_pcl64(raw, 0.1)
+    assert np.array_equal(c.voxel_point_ids64(), vidx) and np.array_equal(c.voxel_out_ids64(), ovox) and np.array_equal(c.download(), ds)
+    c32 = api.Cloud(ctx, raw)
+    c32.voxel_downsample(0.1, "pcl")
+    assert np.array_equal(c32.download(), ds) and np.array_equal(c32.voxel_point_ids().astype(np.int64), vidx)   # same arithmetic where int32 suffices
+    with pytest.raises(api.SlamFusionError):
+        c.voxel_point_ids()                                   # the 32-bit getter refuses 64-bit ids
+    rng = np.random.default_rng(0)
+    big = np.concatenate([rng.uniform(0, 2, (20000, 3)), rng.uniform(0, 2, (20000, 3)) + [2500.0, 1800.0, 900.0]]).astype(np.float32)
+    c = api.Cloud(ctx, big)
+    assert c.voxel_downsample(0.1, "pcl") == api.SF_FLAG_VOXEL_OVERFLOW and len(c) == len(big)     # PCL gives up
+    assert c.voxel_downsample(0.1, "pcl64") == 0
+    ds, vidx, ovox = orc.voxel_pcl64(big, 0.1)
+    assert ovox.max() > 2**31
+    assert np.array_equal(c.voxel_point_ids64(), vidx) and np.array_equal(c.voxel_out_ids64(), ovox) and np.array_equal(c.download(), ds)
+
+
+def test_normals_covariance_matches_oracle(api, ctx, orc, small_world):
+    m = small_world["map"]
+    mp = api.Map(ctx, api.Cloud(ctx, m), 0.25)
+    with pytest.raises(api.SlamFusionError):
+        mp.download_covariances()
+    for radius in (0.25, 0.4):
+        mp.estimate_normals(radius, covariance=True)
+        gn, gc = mp.download_normals()
+        cov = mp.download_covariances()
+        on, oc, ocov = orc.normals_radius_cov(m, radius)
+        assert np.array_equal(gc, oc)
+        scale = np.abs(ocov).max()
+        assert np.abs(cov - ocov).max() <= 1e-12 * scale            # same float64 sums up to the order of the neighbours
+        assert np.array_equal(cov[gc < 3], np.zeros_like(cov[gc < 3]))
+        # the normal is the eigenvector of the exported covariance's smallest eigenvalue
+        k = np.nonzero(gc >= 6)[0][::97]
+        C = np.zeros((len(k), 3, 3))
+        C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2] = cov[k].T
+        C = C + np.transpose(C, (0, 2, 1)) - np.einsum("nij,ij->nij", C, np.eye(3))
+        w, v = np.linalg.eigh(C)
+        well = (w[:, 1] - w[:, 0]) > 1e-6 * w[:, 2]
+        assert (np.abs(np.einsum("ni,ni->n", v[:, :, 0], gn[k].astype(np.float64)))[well] > 1 - 1e-5).all()
+    mp.estimate_normals(0.25)                                       # without the flag the export is gone again
+    with pytest.raises(api.SlamFusionError):
+        mp.download_covariances()
+
+
+def test_pointcloud2_message_contract(api, ctx):
+    rng = np.random.default_rng(4)
+    xyz = rng.normal(size=(3 * 700, 3)).astype(np.float32)
+    fields = [SimpleNamespace(name="x", offset=0, datatype=7), SimpleNamespace(name="y", offset=4, datatype=7), SimpleNamespace(name="z", offset=8, datatype=7)]
+    # organised cloud with padded rows: height 3, width 700, row_step > width * point_step
+    step, width, height = 16, 700, 3
+    row_step = width * step + 40
+    buf = np.zeros((height, row_step), np.uint8)
+    rows = xyz.reshape(height, width, 3)
+    for r in range(height):
+        pts = np.zeros((width, step), np.uint8)
+        pts[:, :12] = rows[r].copy().view(np.uint8).reshape(-1, 12)
+        buf[r, : width * step] = pts.reshape(-1)
+    msg = SimpleNamespace(width=width, height=height, point_step=step, row_step=row_step, is_bigendian=False, data=buf.tobytes(), fields=fields)
+    assert np.array_equal(api.Cloud(ctx).from_pointcloud2(msg).download(), xyz)
+    # FLOAT64 fields are rounded to float32
+    f64 = rng.normal(size=(500, 3))
+    f8 = [SimpleNamespace(name=n, offset=8 * k, datatype=8) for k, n in enumerate("xyz")]
+    msg64 = SimpleNamespace(width=500, height=1, point_step=24, row_step=0, is_bigendian=False, data=f64.tobytes(), fields=f8)
+    assert np.array_equal(api.Cloud(ctx).from_pointcloud2(msg64).download(), f64.astype(np.float32))
+    # short buffer, big-endian payload, mixed or integer datatypes: refused, nothing is read out of bounds
+    short = SimpleNamespace(width=width, height=height, point_step=step, row_step=row_step, is_bigendian=False, data=buf.tobytes()[:-100], fields=fields)
+    with pytest.raises(api.SlamFusionError):
+        api.Cloud(ctx).from_pointcloud2(short)
+    with pytest.raises(api.SlamFusionError):
+        api.Cloud(ctx).from_pointcloud2(SimpleNamespace(width=500, height=1, point_step=24, row_step=0, is_bigendian=True, data=f64.tobytes(), fields=f8))
+    mixed = [SimpleNamespace(name="x", offset=0, datatype=7), SimpleNamespace(name="y", offset=4, datatype=8), SimpleNamespace(name="z", offset=12, datatype=7)]
+    with pytest.raises(api.SlamFusionError):
+        api.Cloud(ctx).from_pointcloud2(SimpleNamespace(width=10, height=1, point_step=24, row_step=0, is_bigendian=False, data=bytes(240), fields=mixed))
+    ints = [SimpleNamespace(name=n, offset=4 * k, datatype=5) for k, n in enumerate("xyz")]
+    with pytest.raises(api.SlamFusionError):
+        api.Cloud(ctx).from_pointcloud2(SimpleNamespace(width=10, height=1, point_step=12, row_step=0, is_bigendian=False, data=bytes(120), fields=ints))
+    empty = SimpleNamespace(width=0, height=0, point_step=12, row_step=0, is_bigendian=False, data=b"", fields=fields)
+    assert len(api.Cloud(ctx).from_pointcloud2(empty)) == 0
+
+
+def test_per_scan_preprocessing_reuses_buffers(api, ctx, orc, small_world):
+    """The crops ping-pong between two persistent buffers (no hipMalloc per scan): a sequence of
+    crops on one cloud object, repeated over several 'scans', must keep matching the oracle."""
+    m = small_world["map"]
+    c = api.Cloud(ctx)
+    rng = np.random.default_rng(1)
+    for k in range(4):
+        pts = (m[rng.permutation(len(m))[: 20000 + 1000 * k]] + np.float32(0.01 * k)).astype(np.float32)
+        c.upload(pts)
+        exp = orc.uniform_subsample(pts, 2)
+        c.subsample(2)
+        assert np.array_equal(c.download(), exp)
+        exp, idx = orc.crop_radius(exp, np.zeros(3, np.float32), 4.0)
+        c.crop_radius(np.zeros(3, np.float32), 4.0, sorted=False)
+        assert np.array_equal(c.last_indices(), np.sort(idx))
+        exp = exp[np.argsort(idx, kind="stable")]
+        assert np.array_equal(c.download(), exp)
+        exp2 = orc.remove_floor(exp)
+        c.remove_floor()
+        assert np.array_equal(c.download(), exp2)

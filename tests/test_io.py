@@ -137,3 +137,80 @@ def test_pointcloud2_unpack_on_device(api, ctx):
     msg3 = SimpleNamespace(width=len(xyz), height=1, point_step=20, data=buf3.tobytes(),
                            fields=[SimpleNamespace(name="z", offset=2), SimpleNamespace(name="x", offset=7), SimpleNamespace(name="y", offset=13)])
     assert np.array_equal(api.Cloud(ctx).from_pointcloud2(msg3).download(), xyz, equal_nan=True)
+
+
+def test_pcd_malformed_headers_are_errors_not_crashes(api, tmp_path):
+    """The PCD header is untrusted input: every malformed case must come back as a
+    SlamFusionError through the C ABI -- no exception through extern "C", no huge allocation, no
+    out-of-bounds read."""
+    base = "VERSION 0.7\nFIELDS x y z\nSIZE %s\nTYPE %s\nCOUNT %s\nWIDTH %s\nHEIGHT %s\nPOINTS %s\nDATA %s\n"
+    body = np.zeros(30, np.float32).tobytes()
+    cases = {
+        "neg_points": base % ("4 4 4", "F F F", "1 1 1", "10", "1", "-5", "binary"),
+        "huge_points": base % ("4 4 4", "F F F", "1 1 1", "10", "1", "999999999999999", "binary"),
+        "huge_width": base % ("4 4 4", "F F F", "1 1 1", "4000000000", "4000000000", "", "binary"),
+        "zero_size": base % ("0 4 4", "F F F", "1 1 1", "10", "1", "10", "binary"),
+        "neg_size": base % ("-4 4 4", "F F F", "1 1 1", "10", "1", "10", "binary"),
+        "zero_count": base % ("4 4 4", "F F F", "0 1 1", "10", "1", "10", "binary"),
+        "int_xyz": base % ("4 4 4", "I I I", "1 1 1", "10", "1", "10", "binary"),
+        "odd_size": base % ("3 4 4", "F F F", "1 1 1", "10", "1", "10", "binary"),
+        "truncated_binary": base % ("4 4 4", "F F F", "1 1 1", "100", "1", "100", "binary"),
+        "truncated_compressed_header": base % ("4 4 4", "F F F", "1 1 1", "10", "1", "10", "binary_compressed"),
+        "unknown_data": base % ("4 4 4", "F F F", "1 1 1", "10", "1", "10", "zip"),
+    }
+    for name, header in cases.items():
+        path = tmp_path / (name + ".pcd")
+        payload = b"\x01\x02" if name == "truncated_compressed_header" else body
+        open(path, "wb").write(header.encode() + payload)
+        with pytest.raises(api.SlamFusionError):
+            api.pcd_read(str(path))
+    # fewer FIELDS than SIZE tokens, no z field
+    open(tmp_path / "nofield.pcd", "wb").write(b"VERSION 0.7\nFIELDS x y\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA ascii\n1 2 3\n4 5 6\n")
+    with pytest.raises(api.SlamFusionError):
+        api.pcd_read(str(tmp_path / "nofield.pcd"))
+    # compressed block whose declared compressed size is absurd
+    hdr = (base % ("4 4 4", "F F F", "1 1 1", "10", "1", "10", "binary_compressed")).encode()
+    open(tmp_path / "bigcomp.pcd", "wb").write(hdr + struct.pack("<II", 0xF0000000, 120) + b"\x00" * 64)
+    with pytest.raises(api.SlamFusionError):
+        api.pcd_read(str(tmp_path / "bigcomp.pcd"))
+    # float64 x y z is legal
+    xyz = np.arange(12, dtype=np.float64).reshape(4, 3)
+    open(tmp_path / "f8.pcd", "wb").write((base % ("8 8 8", "F F F", "1 1 1", "4", "1", "4", "binary")).encode() + xyz.tobytes())
+    assert np.array_equal(api.pcd_read(str(tmp_path / "f8.pcd")), xyz.astype(np.float32))
+
+
+def test_map_data_saver_writes_what_the_recorder_writes(api, tmp_path):
+    """MapDataSaver (mapping/src/map_data_save_node.cpp:12-29,61-112): folder re-created, header lines,
+    one tile every 10 clouds named by the running counter, default-ostream odometry rows, %.8f GPS rows,
+    the open tile flushed on shutdown; and GlobalMapFramesManager reads all of it back."""
+    folder = tmp_path / "map_data"
+    folder.mkdir()
+    (folder / "stale.txt").write_text("left over from an earlier recording")
+    rec = api.MapDataSaver(str(folder))
+    assert not (folder / "stale.txt").exists()
+    rng = np.random.default_rng(3)
+    clouds, odom, lla, yaws = [], [], [], []
+    for k in range(23):
+        c = rng.normal(size=(int(rng.integers(5, 40)), 3)).astype(np.float32)
+        o = rng.normal(0, 0.02, 3)
+        g = (-22.9068 + rng.normal(0, 1e-6), -43.1729 + rng.normal(0, 1e-6), 12.0 + rng.normal(0, 0.2))
+        hdg = float(rng.uniform(0, 360))
+        rec.compassCallback(hdg)
+        yaw = (90.0 - hdg) * np.pi / 180.0
+        yaw = yaw - 2 * np.pi if yaw > np.pi else (yaw + 2 * np.pi if yaw < -np.pi else yaw)
+        assert rec.current_compass_yaw == yaw
+        rec.mappingCallback(c, o, *g)
+        clouds.append(c); odom.append(o); lla.append(g); yaws.append(yaw)
+    rec.onShutdown()
+    names = sorted(p.name for p in folder.iterdir())
+    assert names == ["cloud_10.pcd", "cloud_20.pcd", "cloud_23.pcd", "gps_imu_poses.txt", "odometry_positions.txt"]
+    assert np.array_equal(api.pcd_read(str(folder / "cloud_10.pcd")), np.concatenate(clouds[:10]))
+    assert np.array_equal(api.pcd_read(str(folder / "cloud_20.pcd")), np.concatenate(clouds[10:20]))
+    assert np.array_equal(api.pcd_read(str(folder / "cloud_23.pcd")), np.concatenate(clouds[20:]))
+    lines = (folder / "odometry_positions.txt").read_text().splitlines()
+    assert lines[0] == "tx ty tz" and len(lines) == 24
+    assert lines[1:] == ["%g %g %g" % tuple(o) for o in odom]                 # default ostream formatting = %g (6 significant digits)
+    lines = (folder / "gps_imu_poses.txt").read_text().splitlines()
+    assert lines[0] == "lat lon alt y" and lines[1:] == ["%.8f %.8f %.8f %.8f" % (g[0], g[1], g[2], y) for g, y in zip(lla, yaws)]
+    fm = api.GlobalMapFramesManager(str(folder), "map", 50)
+    assert np.isfinite(fm.getMapTGlobal()).all() and len(fm.altitude_table()) == 23

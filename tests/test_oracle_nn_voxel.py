@@ -150,3 +150,53 @@ def test_normals_against_numpy_eigh(orc):
             P = plane[nb].astype(np.float64)
             w, v = np.linalg.eigh(np.cov(P.T, bias=True))
             assert abs(abs(v[:, 0] @ nrm[i]) - 1) < 1e-5
+
+
+def test_voxel_pcl64_equals_pcl_and_survives_int32_overflow(orc, synth):
+    """The int64-index voxel grid (extension for maps past 2^31 voxels) is the SAME arithmetic:
+    identical ids / order / centroids wherever pcl::VoxelGrid does not overflow; where PCL gives
+    up ("Leaf size is too small") it still filters, and every centroid is the float32 mean of the
+    points that share its cell."""
+    raw = synth.make_map(60_000)
+    raw[5] = [np.nan, 0, 0]
+    a, vidx, ovox, st = orc.voxel_pcl(raw, 0.1)
+    b, vidx64, ovox64 = orc.voxel_pcl64(raw, 0.1)
+    assert st == 0 and np.array_equal(a, b) and np.array_equal(vidx.astype(np.int64), vidx64) and np.array_equal(ovox.astype(np.int64), ovox64)
+    rng = np.random.default_rng(0)
+    big = np.concatenate([rng.uniform(0, 1, (2000, 3)), rng.uniform(0, 1, (2000, 3)) + [2500.0, 1800.0, 900.0]]).astype(np.float32)
+    _, _, _, st = orc.voxel_pcl(big, 0.1)
+    assert st == -1                                                        # PCL: output = input
+    c, pid, oid = orc.voxel_pcl64(big, 0.1)
+    assert oid.max() > 2**31 and np.all(np.diff(oid) > 0) and len(c) < len(big)
+    inv = np.float32(1.0) / np.float32(0.1)
+    ijk = np.floor(big * inv).astype(np.int64)
+    ijk -= ijk.min(0)
+    dims = ijk.max(0) + 1
+    lin = ijk[:, 0] + ijk[:, 1] * dims[0] + ijk[:, 2] * dims[0] * dims[1]
+    assert np.array_equal(lin, pid)
+    for k in (0, len(oid) // 2, len(oid) - 1):
+        members = big[pid == oid[k]]
+        s = np.zeros(3, np.float32)
+        for p in members:
+            s = s + p
+        assert np.array_equal(c[k], s / np.float32(len(members)))
+
+
+def test_normals_covariance_against_numpy(orc, synth):
+    raw = synth.make_map(20_000)
+    m = orc.voxel_pcl(raw, 0.1)[0]
+    nrm, cnt, cov = orc.normals_radius_cov(m, 0.3)
+    nrm2, cnt2 = orc.normals_radius(m, 0.3)
+    assert np.array_equal(nrm, nrm2) and np.array_equal(cnt, cnt2)
+    from scipy.spatial import cKDTree
+    tree = cKDTree(m.astype(np.float64))
+    for i in (0, 17, 500, len(m) - 1):
+        nb = m[tree.query_ball_point(m[i].astype(np.float64), 0.3 + 1e-12)].astype(np.float64)
+        d2 = ((nb - m[i].astype(np.float64)) ** 2).sum(1)
+        nb = nb[d2 <= 0.3 * 0.3]
+        assert len(nb) == cnt[i]
+        if len(nb) >= 3:
+            C = np.cov(nb.T, bias=True)
+            assert np.allclose(cov[i], [C[0, 0], C[0, 1], C[0, 2], C[1, 1], C[1, 2], C[2, 2]], rtol=1e-9, atol=1e-15)
+            w, v = np.linalg.eigh(C)
+            assert abs(abs(v[:, 0] @ nrm[i]) - 1) < 1e-5
