@@ -352,21 +352,28 @@ void sf_sfilter_apply_gaussian_filter(const sf_sfilter *f, const float prev[16],
 
 /* f-4 (EXTENSION, no reference counterpart): error-state EKF pose prior with IMU pre-integration.
  * The reference has no EKF and never reads the IMU (SURVEY.md "Read this first"); its prior is the
- * blend + StochasticFilter above.  State: position, velocity (map frame), attitude R (map <- sensor),
- * 9x9 covariance over (dp, dv, dtheta), attitude error on the right.  Host code, float64, row-major. */
+ * blend + StochasticFilter above.  Nominal state: position, velocity (map frame), attitude R (map <- sensor),
+ * gyro bias, accelerometer bias; 15x15 covariance over (dp, dv, dtheta, dbg, dba), attitude error on the right.
+ * Host code, float64, row-major.  After sf_ekf_reset the bias states carry zero variance and zero random walk, i.e.
+ * the filter is the 9-state (p, v, theta) one until sf_ekf_set_bias / sf_ekf_set_bias_noise give them room. */
 typedef struct sf_ekf sf_ekf;
 int sf_ekf_create(sf_ekf **out);
 void sf_ekf_destroy(sf_ekf *e);
 int sf_ekf_reset(sf_ekf *e, const double T[16], const double v[3] /* or NULL */, const double P_diag[9] /* or NULL: identity */);
 int sf_ekf_set_noise(sf_ekf *e, double gyro_sigma, double accel_sigma, const double gravity[3] /* or NULL: (0, 0, -9.80665) */);
+/* bias estimates and their variances (any argument may be NULL = unchanged); bias random walks per sqrt(second) */
+int sf_ekf_set_bias(sf_ekf *e, const double gyro_bias[3], const double accel_bias[3], const double gyro_bias_var[3], const double accel_bias_var[3]);
+int sf_ekf_set_bias_noise(sf_ekf *e, double gyro_bias_walk, double accel_bias_walk);
 /* n IMU samples (rad/s, specific force m/s^2 in the sensor frame) of period dt, integrated one by one */
 int sf_ekf_predict_imu(sf_ekf *e, const double *gyro, const double *accel, int64_t n, double dt);
-/* the reference's prediction (localization_node.cpp:89-110) as an EKF step: pose <- pose * (prev^-1 cur) */
+/* the reference's prediction (localization_node.cpp:89-110) as an EKF step: pose <- pose * (prev^-1 cur), covariance
+ * through the step's Jacobian (dp <- -R [d_t]x dtheta, dtheta <- d_R^T dtheta) plus the odometry noise */
 int sf_ekf_predict_odometry(sf_ekf *e, const double odom_T_prev[16], const double odom_T_cur[16], const double cov_pos[3], const double cov_rot[3]);
 int sf_ekf_update_position(sf_ekf *e, const double p_map[3], const double cov[9]);   /* GPS, already in the map frame (sf_fusion_gps_pose) */
 int sf_ekf_update_yaw(sf_ekf *e, double yaw, double var);                            /* compass (sf_fusion_compass_to_yaw) */
 int sf_ekf_update_pose(sf_ekf *e, const double T[16], const double cov_pos[3], const double cov_rot[3]);  /* ICP result */
-int sf_ekf_get(const sf_ekf *e, double T[16], double v[3], double P[81]);            /* any output may be NULL */
+int sf_ekf_get(const sf_ekf *e, double T[16], double v[3], double P[81]);            /* any output may be NULL; P = the (dp, dv, dtheta) block */
+int sf_ekf_get_full(const sf_ekf *e, double gyro_bias[3], double accel_bias[3], double P[225]); /* biases and the whole 15x15 covariance */
 
 #ifdef __cplusplus
 }

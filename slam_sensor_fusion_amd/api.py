@@ -198,6 +198,11 @@ class Cloud:
         _check(self.lib.sf_cloud_copy(c.h, self.h))
         return c
 
+    def copy_from(self, other):
+        """device-to-device copy into this cloud's own (persistent) buffer"""
+        _check(self.lib.sf_cloud_copy(self.h, other.h))
+        return self
+
     def subsample(self, step):                       # applyUniformSubsample
         _check(self.lib.sf_cloud_subsample(self.h, C.c_int(step)))
         return self
@@ -770,6 +775,19 @@ class Ekf:
     def set_noise(self, gyro_sigma, accel_sigma, gravity=None):
         g = None if gravity is None else _f64(gravity).reshape(3)
         _check(self.lib.sf_ekf_set_noise(self.h, C.c_double(gyro_sigma), C.c_double(accel_sigma), _p(g) if g is not None else None))
+
+    def set_bias(self, gyro_bias=None, accel_bias=None, gyro_bias_var=None, accel_bias_var=None):
+        args = [None if a is None else _f64(a).reshape(3) for a in (gyro_bias, accel_bias, gyro_bias_var, accel_bias_var)]
+        _check(self.lib.sf_ekf_set_bias(self.h, *[_p(a) if a is not None else None for a in args]))
+
+    def set_bias_noise(self, gyro_bias_walk, accel_bias_walk):
+        _check(self.lib.sf_ekf_set_bias_noise(self.h, C.c_double(gyro_bias_walk), C.c_double(accel_bias_walk)))
+
+    def full_state(self):
+        """-> (gyro bias, accelerometer bias, 15x15 covariance over dp, dv, dtheta, dbg, dba)"""
+        bg, ba, P = np.empty(3), np.empty(3), np.empty(225)
+        _check(self.lib.sf_ekf_get_full(self.h, _p(bg), _p(ba), _p(P)))
+        return bg, ba, P.reshape(15, 15)
 
     def predict_imu(self, gyro, accel, dt):
         gyro, accel = _f64(gyro).reshape(-1, 3), _f64(accel).reshape(-1, 3)

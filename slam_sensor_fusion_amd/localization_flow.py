@@ -18,6 +18,7 @@ class LocalizationFlow:
     # localization_node.h:142,145 and localization_node.cpp:19-35
     ref_frame_distance_ = 3.0
     cloud_crop_radius_ = 10.0
+    icp_mode_ = "ref_cpp"              # ICPPointToPoint::calculateAlignment (icp_point_to_point.cpp:185-254)
 
     def __init__(self, ctx, map_points, map_T_global, altitude_table=None, map_is_downsampled=True):
         self.ctx = ctx
@@ -46,6 +47,8 @@ class LocalizationFlow:
         self.have_window_ = False
         self.current_compass_yaw_ = 0.0
         self.first_time_ = True
+        self.scan_cloud_ = None
+        self.imu_ = None
         self.last = {}
 
     def compassCallback(self, compass_deg):                  # :62-77
@@ -98,9 +101,11 @@ class LocalizationFlow:
         self.map_T_sensor_ = bf.getBestTransformation()
         return True
 
-    def localizationCallback(self, scan_xyz, gps, odom):
+    def localizationCallback(self, scan_xyz, gps, odom, imu=None):
         """gps = dict(latitude, longitude, altitude, position_covariance[9]);
-        odom = dict(q_wxyz, t, covariance[36]).  Returns map_T_sensor or None when gated."""
+        odom = dict(q_wxyz, t, covariance[36]); imu (extension flows only) = dict(gyro[n,3], accel[n,3], dt): the
+        samples since the previous scan.  Returns map_T_sensor or None when gated."""
+        self.imu_ = imu
         if gps["altitude"] < 0:                              # :269-276
             return None
         odom_T_sensor_current = api.quat_to_pose(odom["q_wxyz"], odom["t"])
@@ -112,7 +117,13 @@ class LocalizationFlow:
             return None
 
         # PREPROCESSING :290-305
-        scan = api.Cloud(self.ctx, scan_xyz)
+        if self.scan_cloud_ is None:
+            self.scan_cloud_ = api.Cloud(self.ctx)           # one device cloud for every scan: its buffers persist
+        scan = self.scan_cloud_
+        if hasattr(scan_xyz, "point_step"):                  # a PointCloud2-like message: unpacked on the device (f-2)
+            scan.from_pointcloud2(scan_xyz)
+        else:
+            scan.upload(scan_xyz)
         scan.subsample(2)
         scan.crop_radius([0.0, 0.0, 0.0], self.cloud_crop_radius_, sorted=True)
         sensor_T_ref = api.mat4f_mul(api.mat4f_inverse(self.map_T_sensor_), self.map_T_ref_)
@@ -132,9 +143,9 @@ class LocalizationFlow:
         prior = self.pose_prior(gps, odom, odom_T_sensor_current)
         self.icp_.set_source(scan)
         self.icp_.set_initial_transformation(prior.astype(np.float32))
-        result = self.icp_.align("ref_cpp")
+        result = self.icp_.align(self.icp_mode_)
         self.map_T_sensor_ = result["T"]                     # no has_converged check, :338
-        self.after_alignment(result)
+        self.after_alignment(result, scan)
         self.odom_T_sensor_previous_ = odom_T_sensor_current  # :341
         self.last.update(prior=prior, icp=result, n_scan=len(scan))
         return self.map_T_sensor_
@@ -150,7 +161,7 @@ class LocalizationFlow:
         self.last = dict(odom=map_T_sensor_odom, gps=map_T_sensor_gps, gains=(odometry_gain, gps_compass_gain))
         return prior
 
-    def after_alignment(self, result):
+    def after_alignment(self, result, scan):
         pass
 
 
@@ -189,6 +200,110 @@ class EkfLocalizationFlow(LocalizationFlow):
         self.last = dict(gps=p_gps)
         return prior.astype(np.float32)
 
-    def after_alignment(self, result):
+    def after_alignment(self, result, scan):
         self.ekf_.update_pose(np.asarray(result["T"], dtype=np.float64), [self.icp_pos_var_] * 3, [self.icp_rot_var_] * 3)
         self.map_T_sensor_ = self.ekf_.state()[0].astype(np.float32)
+
+
+class ImuEkfMappingFlow(EkfLocalizationFlow):
+    """BASELINE config 4 as it is worded: the per-scan orchestration with (i) the 15-state EKF driven by the IMU
+    samples that arrived since the previous scan (sf_ekf_predict_imu: pre-integration with gyro / accelerometer bias
+    states) instead of the odometry delta, GPS + compass + ICP pose as measurements, and (ii) incremental map
+    growth: every registered scan is transformed into the map frame (applyTransformation, float32) and collected;
+    every `grow_every` scans (the recorder's tile cadence, mapping/include/mapping/map_data_save_node.h:72) the
+    collected points are appended to the map cloud (`*map_cloud += *cloud`, global_map_frames_manager.cpp:131), the
+    voxel grid is applied again (:142-146) and the NN index rebuilt -- all on the device.  Not reference behaviour
+    (the reference localises against a fixed map and never reads the IMU); every piece it is built from is."""
+
+    # A map that grows by the vehicle's own registrations inherits every registration error, so the alignment runs to
+    # convergence (the Python twin's registration_icp semantics: NN in every iteration, float64, relative criteria
+    # 1e-6) instead of stopping at the C++ node's 5 cm mean-error rule, which is sized for a fixed surveyed map.
+    # Two more settings follow from the same concern.  Scan points that fall just beyond the frontier of the known map
+    # find the frontier's points as "nearest neighbours" and pull the pose back towards the known side: measured on
+    # the oracle, -4.2 mm per registration at the reference's 0.5 m correspondence distance, -0.2 mm at 0.2 m (the
+    # IMU-driven prior is good to a few cm, so 0.2 m loses nothing); against the stride-3 index of the C++ node
+    # (localization_node.cpp:20) the same pull is -12 mm, so the grown map is indexed at full resolution.
+    icp_mode_ = "o3d_p2p"
+    mapping_icp_iterations_ = 30       # localization_node.py:236
+    mapping_max_corr_ = 0.2
+    icp_pos_var_ = 0.01 ** 2
+    icp_rot_var_ = np.radians(0.1) ** 2
+    grow_every_ = 10
+    voxel_ = 0.1
+    index_stride_ = 1
+    gyro_sigma_, accel_sigma_ = 2e-3, 5e-2
+    gyro_bias_var_, accel_bias_var_ = 1e-4, 1e-2
+    gyro_bias_walk_, accel_bias_walk_ = 1e-5, 1e-4
+    start_velocity_var_ = 1.0
+
+    def __init__(self, ctx, map_points, map_T_global, altitude_table=None, grow_every=None, voxel_flavour="pcl"):
+        super().__init__(ctx, map_points, map_T_global, altitude_table)
+        if grow_every is not None:
+            self.grow_every_ = int(grow_every)
+        self.icp_.set_num_iterations(self.mapping_icp_iterations_)
+        self.icp_.set_max_correspondence_dist(self.mapping_max_corr_)
+        self.index_cloud_ = self.map_cloud_
+        if self.index_stride_ != 3:                           # the parent indexed the stride-3 copy
+            self.index_cloud_ = api.Cloud(ctx, np.asarray(map_points, dtype=np.float32))
+            self.index_cloud_.subsample(self.index_stride_)
+            self.map_index_.build(self.index_cloud_, 0.0)
+            self.map_cloud_ = self.index_cloud_
+            self.icp_.set_target(self.map_index_)
+        self.voxel_flavour_ = voxel_flavour
+        self.map_full_ = api.Cloud(ctx, np.asarray(map_points, dtype=np.float32))   # the voxel-filtered map at full resolution
+        self.pending_ = api.Cloud(ctx, np.zeros((0, 3), np.float32))
+        self.registered_ = api.Cloud(ctx)
+        self.scans_since_growth_ = 0
+        self.growths_ = 0
+        self.on_grow = None                                   # test hook: on_grow(flow) just before a growth step
+
+    def pose_prior(self, gps, odom, odom_T_sensor_current):
+        if not self.ekf_started_:
+            self.ekf_.reset(self.map_T_sensor_.astype(np.float64), None,
+                            [self.start_sigma_m_ ** 2] * 3 + [self.start_velocity_var_] * 3 + [self.start_sigma_rad_ ** 2] * 3)
+            self.ekf_.set_noise(self.gyro_sigma_, self.accel_sigma_, None)
+            self.ekf_.set_bias(None, None, [self.gyro_bias_var_] * 3, [self.accel_bias_var_] * 3)
+            self.ekf_.set_bias_noise(self.gyro_bias_walk_, self.accel_bias_walk_)
+            self.ekf_started_ = True
+        imu = self.imu_
+        if imu is not None and len(imu["gyro"]) > 0:
+            self.ekf_.predict_imu(imu["gyro"], imu["accel"], float(imu["dt"]))
+        else:                                                # no IMU samples for this interval: the odometry delta
+            cov = np.asarray(odom["covariance"], dtype=np.float64).reshape(6, 6)
+            self.ekf_.predict_odometry(self.odom_T_sensor_previous_.astype(np.float64), odom_T_sensor_current.astype(np.float64),
+                                       np.diag(cov)[:3], np.diag(cov)[3:])
+        if "map_xyz" in gps:
+            p_gps = np.asarray(gps["map_xyz"], dtype=np.float64)
+        else:
+            p_gps = self.computeGpsCoarsePoseInMapFrame(gps["latitude"], gps["longitude"])[:3, 3].astype(np.float64)
+        self.ekf_.update_position(p_gps, np.asarray(gps["position_covariance"], dtype=np.float64).reshape(3, 3))
+        self.ekf_.update_yaw(float(self.current_compass_yaw_), self.compass_var_)
+        prior = self.ekf_.state()[0]
+        self.last = dict(gps=p_gps)
+        return prior.astype(np.float32)
+
+    def after_alignment(self, result, scan):
+        super().after_alignment(result, scan)
+        # the registered scan in the map frame, collected on the device
+        self.registered_.copy_from(scan)
+        self.registered_.transform(self.map_T_sensor_)
+        self.pending_.append(self.registered_)
+        self.scans_since_growth_ += 1
+        if self.scans_since_growth_ >= self.grow_every_:
+            self.grow_map()
+
+    def grow_map(self):
+        if self.on_grow is not None:
+            self.on_grow(self)
+        self.map_full_.append(self.pending_)
+        self.map_full_.voxel_downsample(self.voxel_, self.voxel_flavour_)
+        self.index_cloud_.copy_from(self.map_full_)
+        self.index_cloud_.subsample(self.index_stride_)
+        self.map_index_.build(self.index_cloud_, 0.0)
+        self.map_cloud_ = self.index_cloud_
+        self.icp_.set_target(self.map_index_)
+        self.have_window_ = False                             # the rebuilt index has no window yet: set at the next scan
+        self.ref_cropped_map_cloud_ = None
+        self.pending_.upload(np.zeros((0, 3), np.float32))
+        self.scans_since_growth_ = 0
+        self.growths_ += 1

@@ -93,6 +93,37 @@ def make_stream(n_scans, seed=STREAM_SEED):
                 odom_cov=np.diag([1e-4] * 6))
 
 
+def make_imu(n_scans, scan_period=0.1, rate_hz=100, gyro_bias=(0.004, -0.003, 0.002), accel_bias=(0.08, -0.05, 0.06),
+             gyro_sigma=2e-3, accel_sigma=5e-2, seed=STREAM_SEED + 1):
+    """IMU samples for make_stream's truth (0.1 m and 0.1 deg per scan = 1 m/s along +x of the MAP and 1 deg/s of yaw at
+    10 Hz scans; the path is straight while the sensor turns, so the world acceleration is zero): per scan interval
+    k -> k+1 `rate_hz * scan_period` samples of gyro (rad/s) and specific force (m/s^2) in the sensor frame, with
+    constant biases and white noise.  Returns (gyro[n_scans-1, m, 3], accel[n_scans-1, m, 3], dt)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    m = int(round(rate_hz * scan_period))
+    dt = scan_period / m
+    w = np.radians(0.1) / scan_period
+    gyro = np.zeros((n_scans - 1, m, 3))
+    accel = np.zeros((n_scans - 1, m, 3))
+    gyro[..., 2] = w
+    accel[..., 2] = 9.80665                                  # yaw-only attitude: gravity stays on the sensor's z axis
+    gyro += np.asarray(gyro_bias) + rng.normal(0.0, gyro_sigma, gyro.shape)
+    accel += np.asarray(accel_bias) + rng.normal(0.0, accel_sigma, accel.shape)
+    return gyro, accel, dt
+
+
+def make_corridor(length_m, width_m, x0=-12.0, seed=MAP_SEED + 7):
+    """Raw points uniform in [x0, x0 + length] x [-width/2, width/2] x [-5, 5] m at the bench density (100 pts/m^3):
+    the world a config-4 vehicle drives through (make_stream advances along +x)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = int(length_m * width_m * DENSITY)
+    pts = np.empty((n, 3), dtype=np.float32)
+    pts[:, 0] = rng.uniform(x0, x0 + length_m, n)
+    pts[:, 1] = rng.uniform(-width_m / 2, width_m / 2, n)
+    pts[:, 2] = rng.uniform(-5.0, 5.0, n)
+    return pts
+
+
 # ------------------------------------------------------------------ config 5: ring-structured scan vs a city map
 CITY_SEED = 4000
 

@@ -15,7 +15,7 @@ from scipy.spatial.transform import Rotation
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slam_sensor_fusion_amd import api, synth  # noqa: E402
-from slam_sensor_fusion_amd.localization_flow import EkfLocalizationFlow, LocalizationFlow  # noqa: E402
+from slam_sensor_fusion_amd.localization_flow import EkfLocalizationFlow, ImuEkfMappingFlow, LocalizationFlow  # noqa: E402
 
 
 def main():
@@ -23,8 +23,9 @@ def main():
     ap.add_argument("--scans", type=int, default=1000)
     ap.add_argument("--scan-points", type=int, default=60_000)
     ap.add_argument("--map-points", type=int, default=20_000_000)
-    ap.add_argument("--prior", default="reference", choices=["reference", "ekf"],
-                    help="reference: blend + StochasticFilter (localization_node.cpp:318-332); ekf: the sf_ekf extension, GPS given in the map frame")
+    ap.add_argument("--prior", default="reference", choices=["reference", "ekf", "imu-ekf-growth"],
+                    help="reference: blend + StochasticFilter (localization_node.cpp:318-332); ekf: the sf_ekf extension, GPS given in the map frame; "
+                         "imu-ekf-growth: config 4 as worded -- 15-state EKF fed 100 Hz IMU samples + map growth every 10 scans")
     args = ap.parse_args()
     ctx = api.Context(0)
     raw = synth.make_map(args.map_points)
@@ -39,7 +40,8 @@ def main():
     ds[:, 0] += np.float32(L / 2 - 12.0)
     lla0 = np.array([[-22.9068, -43.1729, 12.0]])
     mtg = api.map_T_global(lla0, np.zeros(1, np.float32))
-    flow = (EkfLocalizationFlow if args.prior == "ekf" else LocalizationFlow)(ctx, ds, mtg, altitude_table=lla0)
+    flow = {"reference": LocalizationFlow, "ekf": EkfLocalizationFlow, "imu-ekf-growth": ImuEkfMappingFlow}[args.prior](ctx, ds, mtg, altitude_table=lla0)
+    gyro, accel, imu_dt = synth.make_imu(args.scans)
     flow.coarse_alignment_complete_ = True
     stream = synth.make_stream(args.scans)
     rng = np.random.default_rng(synth.STREAM_SEED)
@@ -60,11 +62,12 @@ def main():
         q = Rotation.from_matrix(odomT[:3, :3]).as_quat()
         odom = dict(q_wxyz=[q[3], q[0], q[1], q[2]], t=odomT[:3, 3], covariance=stream["odom_cov"].ravel())
         gps = dict(latitude=-22.9068, longitude=-43.1729, altitude=12.0, position_covariance=stream["gps_cov"].ravel())
-        if args.prior == "ekf":
+        if args.prior != "reference":
             gps["map_xyz"] = stream["gps_xyz"][k] + start
+        imu = dict(gyro=gyro[k - 1], accel=accel[k - 1], dt=imu_dt) if (args.prior == "imu-ekf-growth" and k > 0) else None
         flow.compassCallback(90.0 - np.degrees(stream["compass"][k]))
         t0 = time.perf_counter()
-        out = flow.localizationCallback(scan, gps, odom)
+        out = flow.localizationCallback(scan, gps, odom, imu=imu)
         ctx.synchronize()
         dt = time.perf_counter() - t0
         if k == 0:
