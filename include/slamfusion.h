@@ -258,6 +258,33 @@ void *sf_icp_exchange_ptr(sf_icp *icp, int64_t *nbytes);
 int sf_icp_step_begin(sf_icp *icp, int mode, int first);
 int sf_icp_step_end(sf_icp *icp, int mode, int last);
 
+/* The same loop driven from the C side (no host work between iterations).  sf_comm is an RCCL communicator bound to a
+ * context's stream; RCCL is resolved at run time (sf_comm_load_rccl: path of the library the process must share, NULL =
+ * the already loaded one or librccl.so.1).  Rank 0 draws sf_comm_unique_id (128 bytes), the launcher (torch.distributed,
+ * MPI, a file) hands it to every rank, each rank calls sf_comm_create. */
+typedef struct sf_comm sf_comm;
+int sf_comm_load_rccl(const char *library_path);
+int sf_comm_unique_id(void *id128);
+int sf_comm_create(sf_ctx *ctx, int nranks, int rank, const void *id128, sf_comm **out);
+void sf_comm_destroy(sf_comm *c);
+int sf_comm_size(const sf_comm *c, int *nranks, int *rank);
+int sf_comm_allreduce_f64(sf_comm *c, void *d_buf, int64_t count); /* in place, on the context's stream (barriers, timing) */
+/* one whole pass (every iteration) enqueued; first = 1 start, 2 resume the scans that stopped stale */
+int sf_icp_align_sharded_async(sf_icp *icp, int mode, sf_comm *comm, int first);
+/* blocking: passes until no scan is stale (identical decisions on every rank), results like sf_icp_align_batch */
+int sf_icp_align_sharded(sf_icp *icp, int mode, sf_comm *comm, sf_icp_result *out, int *resumes /* or NULL */);
+/* several slabs held by ONE process on one device and context (members[m]: slab m + halo indexed, sf_icp_set_shard given,
+ * same source batch and initial transforms): lockstep on the stream, the all-reduce is a device sum in member order */
+int sf_icp_align_group(sf_icp **members, int n_members, int mode, sf_icp_result *out, int *resumes /* or NULL */);
+/* owned-query candidates of this rank per scan in the last sharded alignment */
+int sf_icp_owned_counts(sf_icp *icp, int64_t *counts, int cap);
+/* Routing ("all-reduce only when the submap spans tiles"): the slabs [lo[b], hi[b]] scan b can reach -- the x-extent of its
+ * bounding box under its initial pose (inits: batch x 16 doubles or NULL) widened by margin, against the slab edges
+ * (n_slabs + 1 ascending values, first -inf, last +inf).  lo == hi: one rank registers the scan alone, unsharded, no
+ * collective; otherwise the ranks lo..hi do, on a communicator of just those ranks.  hi < lo: no finite point. */
+int sf_shard_route(const float *xyz, int64_t n_per_scan, int batch, const double *inits, const double *edges, int n_slabs, double margin,
+                   int32_t *lo, int32_t *hi);
+
 /* profiling: wraps every NN kernel of the following aligns in hipEvents on the context
  * stream; sf_icp_profile_read returns launches and summed milliseconds since enabling. */
 int sf_icp_profile_enable(sf_icp *icp, int on);

@@ -45,7 +45,7 @@ _live = weakref.WeakSet()   # every wrapper object, closed in dependency order a
 
 
 def _close_all():
-    for kind in ("Icp", "BruteForceAlignment", "Map", "Cloud", "Context"):
+    for kind in ("Comm", "Icp", "BruteForceAlignment", "Map", "Cloud", "Context"):
         for obj in [o for o in list(_live) if type(o).__name__ == kind]:
             try:
                 obj.close()
@@ -503,6 +503,22 @@ class Icp:
     def step_end(self, mode, last):
         _check(self.lib.sf_icp_step_end(self.h, C.c_int(MODES[mode]), C.c_int(int(last))))
 
+    def align_sharded(self, mode, comm):
+        """The whole sharded alignment from the C side (RCCL all-reduce per iteration on the context's stream)."""
+        arr = (IcpResult * self.batch)()
+        resumes = C.c_int()
+        _check(self.lib.sf_icp_align_sharded(self.h, C.c_int(MODES[mode]), comm.h, arr, C.byref(resumes)))
+        self.resumes = resumes.value
+        return [r.as_dict() for r in arr]
+
+    def align_sharded_async(self, mode, comm, first=1):
+        _check(self.lib.sf_icp_align_sharded_async(self.h, C.c_int(MODES[mode]), comm.h, C.c_int(first)))
+
+    def owned_counts(self):
+        out = np.empty(self.batch, np.int64)
+        _check(self.lib.sf_icp_owned_counts(self.h, _p(out), C.c_int(self.batch)))
+        return out
+
     def profile_enable(self, on=True):
         _check(self.lib.sf_icp_profile_enable(self.h, C.c_int(int(on))))
 
@@ -514,6 +530,79 @@ class Icp:
     def close(self):
         if self.h:
             self.lib.sf_icp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def align_group(members, mode):
+    """Several slabs of one map held by this process on one device (sf_icp_align_group) -> (results, resumes)."""
+    n = len(members)
+    arr = (IcpResult * members[0].batch)()
+    hs = (C.c_void_p * n)(*[m.h for m in members])
+    resumes = C.c_int()
+    _check(load_library().sf_icp_align_group(hs, C.c_int(n), C.c_int(MODES[mode]), arr, C.byref(resumes)))
+    return [r.as_dict() for r in arr], resumes.value
+
+
+def shard_route(scans, inits, edges, margin):
+    """Slab range [lo, hi] of every scan (sf_shard_route)."""
+    scans = _f32(scans)
+    assert scans.ndim == 3 and scans.shape[2] == 3
+    B = scans.shape[0]
+    T = None if inits is None else _f64(inits).reshape(B, 16)
+    e = _f64(edges)
+    lo, hi = np.empty(B, np.int32), np.empty(B, np.int32)
+    _check(load_library().sf_shard_route(_p(scans), C.c_int64(scans.shape[1]), C.c_int(B), _p(T) if T is not None else None, _p(e), C.c_int(len(e) - 1),
+                                         C.c_double(margin), _p(lo), _p(hi)))
+    return lo, hi
+
+
+def rccl_library_path():
+    """The RCCL the process must share: the one inside the torch wheel when torch is importable (its HIP runtime is
+    the one this process uses, see load_library), else the system's."""
+    try:
+        import torch
+        p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(p):
+            return p
+    except ImportError:
+        pass
+    return None
+
+
+class Comm:
+    """sf_comm: an RCCL communicator on a context's stream, created from a 128-byte unique id."""
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        path = rccl_library_path()
+        _check(lib.sf_comm_load_rccl(path.encode() if path else None))
+        buf = (C.c_char * 128)()
+        _check(lib.sf_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, ctx, nranks, rank, unique_id):
+        self.ctx, self.lib = ctx, ctx.lib
+        path = rccl_library_path()
+        _check(self.lib.sf_comm_load_rccl(path.encode() if path else None))
+        self.h = C.c_void_p()
+        assert len(unique_id) == 128
+        _check(self.lib.sf_comm_create(ctx.h, C.c_int(nranks), C.c_int(rank), C.c_char_p(unique_id) if False else (C.c_char * 128).from_buffer_copy(unique_id), C.byref(self.h)))
+        self.nranks, self.rank = nranks, rank
+        _live.add(self)
+
+    def allreduce_f64(self, ptr, count):
+        _check(self.lib.sf_comm_allreduce_f64(self.h, C.c_void_p(ptr), C.c_int64(count)))
+
+    def close(self):
+        if self.h:
+            self.lib.sf_comm_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

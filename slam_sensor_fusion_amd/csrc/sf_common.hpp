@@ -153,7 +153,12 @@ struct sf_map {
     SfWindow window{};
 };
 
+struct sf_comm;
+
 namespace sf {
+// sf_shard.cpp: in-place float64 sum over the communicator, enqueued on its context's stream
+int comm_allreduce_f64(sf_comm *c, void *d_buf, int64_t count);
+sf_ctx *comm_ctx(const sf_comm *c);
 // device-side helpers implemented in sf_cloud.hip, used across TUs
 int compact_cloud(sf_cloud *c, const uint8_t *d_flags);
 int ensure_scratch(sf_ctx *ctx, size_t bytes);

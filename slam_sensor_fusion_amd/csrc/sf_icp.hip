@@ -1831,6 +1831,143 @@ extern "C" int sf_icp_step_end(sf_icp *icp, int mode, int last)
     return SF_OK;
 }
 
+// ------------------------------------------------------------------ sharded alignment driven from the C side
+// One rank's whole alignment: per iteration NN + slab reduce (sf_icp_step_begin), the all-reduce of the batch's
+// exchange records on the context's stream, the identical solve on every rank (sf_icp_step_end) -- enqueued
+// back to back, no host involvement between iterations.  The `sum` callback is the collective: RCCL
+// (sf_icp_align_sharded) or, for several slabs held by ONE process on one device, a fixed-order device sum
+// (sf_icp_align_group).
+namespace {
+
+constexpr int GROUP_MAX = 16;
+struct GroupBufs { double *p[GROUP_MAX]; int n; };
+
+// every member's buffer <- sum over the members, in member order (bitwise deterministic)
+__global__ void k_group_sum(GroupBufs g, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double s = 0.0;
+    for (int m = 0; m < g.n; ++m) s += g.p[m][i];
+    for (int m = 0; m < g.n; ++m) g.p[m][i] = s;
+}
+
+int sharded_steps(const sf_icp *icp, int mode) { return mode == SF_ICP_O3D_P2P ? icp->prm.num_iters + 1 : icp->prm.num_iters; }
+
+bool any_stale(const sf_icp *icp)
+{
+    for (int b = 0; b < icp->batch; ++b)
+        if (icp->h_state[(size_t)b].flags & SF_ICP_FLAG_SHARD_STALE) return true;
+    return false;
+}
+
+int fetch_states(sf_icp *icp)
+{
+    hipStream_t s = icp->ctx->stream;
+    SF_HIP(hipMemcpyAsync(icp->h_state.data(), icp->state.p, sizeof(IcpState) * (size_t)icp->batch, hipMemcpyDeviceToHost, s));
+    SF_HIP(hipStreamSynchronize(s));
+    if (icp->profiling) prof_collect(icp);
+    return SF_OK;
+}
+
+} // namespace
+
+extern "C" int sf_icp_align_sharded_async(sf_icp *icp, int mode, sf_comm *comm, int first)
+{
+    SF_TRY(check_ready(icp, mode));
+    SF_CHECK(comm && sf::comm_ctx(comm) == icp->ctx, SF_ERR_INVALID, "the communicator must live on the icp's context (same stream)");
+    SF_CHECK(icp->shard, SF_ERR_STATE, "sf_icp_set_shard first");
+    SF_CHECK(first == 1 || first == 2, SF_ERR_INVALID, "first must be 1 (start) or 2 (resume)");
+    const int steps = sharded_steps(icp, mode);
+    for (int k = 0; k < steps; ++k) {
+        SF_TRY(sf_icp_step_begin(icp, mode, k == 0 ? first : 0));
+        SF_TRY(sf::comm_allreduce_f64(comm, sf_icp_exchange_ptr(icp, nullptr), (int64_t)REC_STRIDE * icp->batch));
+        SF_TRY(sf_icp_step_end(icp, mode, k == steps - 1));
+    }
+    return SF_OK;
+}
+
+// blocking form: passes until no scan is left stale (every rank takes the same decisions: the states are identical)
+extern "C" int sf_icp_align_sharded(sf_icp *icp, int mode, sf_comm *comm, sf_icp_result *out, int *resumes)
+{
+    SF_CHECK(out, SF_ERR_INVALID, "out is NULL");
+    int first = 1, n_resume = 0;
+    if (icp) {
+        const int steps = sharded_steps(icp, mode);
+        for (int attempt = 0; attempt <= steps + 1; ++attempt) { // every resume completes at least one iteration
+            SF_TRY(sf_icp_align_sharded_async(icp, mode, comm, first));
+            SF_TRY(fetch_states(icp));
+            if (!any_stale(icp)) {
+                for (int b = 0; b < icp->batch; ++b) fill_result(icp, icp->last_mode, icp->h_state[(size_t)b], &icp->inits[(size_t)b * 16], out + b);
+                if (resumes) *resumes = n_resume;
+                return SF_OK;
+            }
+            first = 2;
+            ++n_resume;
+        }
+    }
+    sf::set_error("sharded alignment did not finish");
+    return SF_ERR_STATE;
+}
+
+// n slabs of one map held by ONE process on one device (members[m] indexes slab m + halo, set_shard(x_lo, x_hi)
+// given, the same source batch and initial transforms on every member, all on the same context): the members step
+// in lockstep on the context's stream and the "all-reduce" is a device sum of their exchange buffers in member
+// order.  Results (identical on every member) are returned from member 0.
+extern "C" int sf_icp_align_group(sf_icp **members, int n, int mode, sf_icp_result *out, int *resumes)
+{
+    SF_CHECK(members && n >= 1 && n <= GROUP_MAX && out, SF_ERR_INVALID, "bad arguments (1..%d members)", GROUP_MAX);
+    GroupBufs gb;
+    gb.n = n;
+    for (int m = 0; m < n; ++m) {
+        SF_TRY(check_ready(members[m], mode));
+        SF_CHECK(members[m]->shard, SF_ERR_STATE, "member %d: sf_icp_set_shard first", m);
+        SF_CHECK(members[m]->ctx == members[0]->ctx && members[m]->batch == members[0]->batch && members[m]->n == members[0]->n &&
+                     members[m]->prm.num_iters == members[0]->prm.num_iters,
+                 SF_ERR_INVALID, "member %d does not match member 0 (context, batch, points per scan, iterations)", m);
+    }
+    sf_icp *lead = members[0];
+    const int steps = sharded_steps(lead, mode), count = REC_STRIDE * lead->batch;
+    hipStream_t s = lead->ctx->stream;
+    int first = 1, n_resume = 0;
+    for (int attempt = 0; attempt <= steps + 1; ++attempt) {
+        for (int k = 0; k < steps; ++k) {
+            for (int m = 0; m < n; ++m) {
+                SF_TRY(sf_icp_step_begin(members[m], mode, k == 0 ? first : 0));
+                gb.p[m] = reinterpret_cast<double *>(sf_icp_exchange_ptr(members[m], nullptr));
+            }
+            hipLaunchKernelGGL(k_group_sum, dim3(nblk(count, 256)), dim3(256), 0, s, gb, count);
+            for (int m = 0; m < n; ++m) SF_TRY(sf_icp_step_end(members[m], mode, k == steps - 1));
+        }
+        SF_HIP(hipGetLastError());
+        for (int m = 0; m < n; ++m) SF_TRY(fetch_states(members[m]));
+        for (int m = 1; m < n; ++m) // the slabs must agree bit for bit: same records in, same solve
+            for (int b = 0; b < lead->batch; ++b)
+                SF_CHECK(std::memcmp(members[m]->h_state[(size_t)b].T, lead->h_state[(size_t)b].T, sizeof(double) * 16) == 0 &&
+                             members[m]->h_state[(size_t)b].flags == lead->h_state[(size_t)b].flags,
+                         SF_ERR_STATE, "slab %d diverged from slab 0 on scan %d", m, b);
+        if (!any_stale(lead)) {
+            for (int b = 0; b < lead->batch; ++b) fill_result(lead, lead->last_mode, lead->h_state[(size_t)b], &lead->inits[(size_t)b * 16], out + b);
+            if (resumes) *resumes = n_resume;
+            return SF_OK;
+        }
+        first = 2;
+        ++n_resume;
+    }
+    sf::set_error("group alignment did not finish");
+    return SF_ERR_STATE;
+}
+
+// queries this rank owned in the LAST iteration of the last sharded alignment, per scan (n_corr of the exchange
+// record before the collective is not kept; this is the owned-candidate count of the compact arrays)
+extern "C" int sf_icp_owned_counts(sf_icp *icp, int64_t *counts, int cap)
+{
+    SF_CHECK(icp && counts && cap >= icp->batch, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(icp->shard && icp->h_own.size() == (size_t)icp->batch + 1, SF_ERR_STATE, "no sharded alignment has run");
+    for (int b = 0; b < icp->batch; ++b) counts[b] = (int64_t)icp->h_own[(size_t)b + 1] - (int64_t)icp->h_own[(size_t)b];
+    return SF_OK;
+}
+
 // ------------------------------------------------------------------ profiling
 extern "C" int sf_icp_profile_enable(sf_icp *icp, int on)
 {

@@ -105,3 +105,75 @@ class PipelinedShardedIcp:
             self.resumes += 1
             first = [2 if s else 0 for s in stale]
         raise RuntimeError("sharded alignment did not finish")
+
+
+# ------------------------------------------------------------------ routing: collectives only where a scan spans slabs
+def contiguous_ranges(world):
+    """Every rank range [lo, hi] with lo < hi, in the order every rank must create / use communicators in."""
+    return [(lo, hi) for lo in range(world) for hi in range(lo + 1, world)]
+
+
+def plan_groups(lo, hi):
+    """Scans grouped by the slab range they touch: {(lo, hi): [scan ids]}, ranges sorted.  Scans without a finite
+    point (hi < lo) are in no group."""
+    groups = {}
+    for b, (a, e) in enumerate(zip(lo, hi)):
+        if e >= a:
+            groups.setdefault((int(a), int(e)), []).append(b)
+    return dict(sorted(groups.items()))
+
+
+class RoutedRegistration:
+    """One rank's side of registering a batch of scans against a map sharded into x-slabs (north_star: "RCCL
+    all-reduce of the normal equations only when the submap spans tiles").
+
+    Every scan is routed to the slabs its bounding box (under its initial pose, widened by `margin`) can reach
+    (`route`, = api.shard_route / sf_shard_route).  A scan inside ONE slab is registered by that slab's rank alone
+    with the unsharded fast path -- no collective, no other rank takes part (the rank's map carries a halo, so every
+    neighbour within the correspondence distance is local).  Scans that span slabs lo..hi are registered by exactly
+    those ranks with the sharded path, all-reducing on a communicator of just those ranks.  Ranks walk the groups in
+    the same sorted order, so communicators shared between ranks see their collectives in the same order.
+
+    make_local()            -> icp-like (set_source_batch, set_initial_batch, align_batch_async, fetch_results)
+    make_sharded(lo, hi)    -> (icp-like with set_shard / set_source_batch / set_initial_batch / align_sharded(mode, comm), comm)
+    """
+
+    def __init__(self, rank, world, edges, route, make_local, make_sharded, margin=1.0):
+        self.rank, self.world, self.edges, self.route = rank, world, np.asarray(edges, dtype=np.float64), route
+        self.make_local, self.make_sharded, self.margin = make_local, make_sharded, margin
+        self.groups, self.mine, self.resumes = {}, {}, 0
+
+    def set_source_batch(self, scans, inits=None):
+        """scans [B, n, 3] (every rank is handed the same batch), inits [B, 4, 4] or None."""
+        scans = np.asarray(scans, dtype=np.float32)
+        lo, hi = self.route(scans, inits, self.edges, self.margin)
+        self.groups = plan_groups(lo, hi)
+        self.mine = {}
+        for (a, e), ids in self.groups.items():
+            if not (a <= self.rank <= e):
+                continue                                      # this rank never sees these scans again
+            if a == e:
+                icp, comm = self.make_local(), None
+            else:
+                icp, comm = self.make_sharded(a, e)
+                icp.set_shard(float(max(self.edges[self.rank], -1e30)), float(min(self.edges[self.rank + 1], 1e30)))
+            icp.set_source_batch(scans[ids])
+            icp.set_initial_batch(None if inits is None else np.asarray(inits, dtype=np.float64)[ids])
+            self.mine[(a, e)] = (icp, comm, ids)
+        return self.groups
+
+    def align(self, mode):
+        """-> {scan id: result} for the scans this rank took part in."""
+        out, self.resumes = {}, 0
+        local = [(k, v) for k, v in self.mine.items() if k[0] == k[1]]
+        for _, (icp, _, _) in local:
+            icp.align_batch_async(mode)                       # no collective: runs while this rank waits in the groups below
+        for (a, e), (icp, comm, ids) in self.mine.items():
+            if a == e:
+                continue
+            res = icp.align_sharded(mode, comm)
+            self.resumes += int(getattr(icp, "resumes", 0))
+            out.update(dict(zip(ids, res)))
+        for _, (icp, _, ids) in local:
+            out.update(dict(zip(ids, icp.fetch_results())))
+        return out

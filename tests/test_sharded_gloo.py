@@ -180,3 +180,151 @@ def test_slab_partition_properties():
             assert len(sel) >= core[r] and x.min() >= edges[r] - 1.0 and x.max() < edges[r + 1] + 1.0
     drv = sharded.ShardedIcp(None, "o3d_p2p", 30, None)
     assert drv.n_steps() == 31                                        # final evaluation after the last update
+
+
+# ------------------------------------------------------------------ routing: collectives only where a scan spans slabs
+class NumpyRoutedIcp:
+    """Stand-in for api.Icp behind sharded.RoutedRegistration on one rank: a batch of scans, local (unsharded) or
+    sharded over a gloo sub-group.  Counts the collectives it issues."""
+
+    def __init__(self, orc, map_pts, normals, log):
+        self.orc, self.map, self.nrm, self.log = orc, map_pts, normals, log
+        self.lo = self.hi = None
+
+    def set_shard(self, lo, hi):
+        self.lo, self.hi = lo, hi
+
+    def set_source_batch(self, scans):
+        self.scans = scans
+        self.inits = [np.eye(4)] * len(scans)
+
+    def set_initial_batch(self, inits):
+        self.inits = [np.eye(4)] * len(self.scans) if inits is None else list(inits)
+
+    def align_batch_async(self, mode):
+        self.results = []
+        for s, T0 in zip(self.scans, self.inits):
+            r = self.orc.icp_p2plane(s, self.map, self.nrm, T0, MAX_DIST, ITERS)
+            self.results.append(dict(T64=r["T"], iterations=r["iterations"], n_corr=r["n_corr"], flags=0))
+        self.log.append(("local", len(self.scans)))
+
+    def fetch_results(self):
+        return self.results
+
+    def align_sharded(self, mode, group):
+        xchg = torch.zeros(32 * len(self.scans), dtype=torch.float64)
+        steps = [NumpyShardStep(self.orc, self.map, self.nrm, s, self.lo, self.hi, xchg[32 * k:32 * (k + 1)]) for k, s in enumerate(self.scans)]
+        for k, st in enumerate(steps):
+            st.step_begin(mode, 1)
+            st.T = np.array(self.inits[k], dtype=np.float64)
+        for it in range(ITERS):
+            for st in steps:
+                st.step_begin(mode, 0)
+            dist.all_reduce(xchg, group=group)                 # one collective per iteration for the whole group, on the sub-group only
+            self.log.append(("allreduce", dist.get_process_group_ranks(group)))
+            for st in steps:
+                st.step_end(mode, it == ITERS - 1)
+        return [dict(T64=st.T, iterations=st.iterations, n_corr=st.n_corr, flags=0) for st in steps]
+
+
+def routed_world(orc, synth, world):
+    """Map, slab edges and a batch of scans: inside one slab, straddling two, over the whole map, and one that starts in
+    one slab and is moved across an edge by its initial pose."""
+    raw = synth.make_map(60_000)
+    ds = orc.voxel_pcl(raw, 0.1)[0]
+    from slam_sensor_fusion_amd import sharded
+    edges = sharded.slab_edges(ds[:, 0], world)
+    rng = np.random.default_rng(5)
+
+    def scan_from(mask, n=1500, T=None, seed=0):
+        pts = ds[mask]
+        return synth.make_scan(pts, n, scan_id=50 + seed, T=T)[0]
+
+    x = ds[:, 0]
+    inner = [0.5 * (max(edges[r], x.min()) + min(edges[r + 1], x.max())) for r in range(world)]
+    scans, inits = [], []
+    r_last = world - 1
+    scans.append(scan_from(np.abs(x - inner[r_last]) < 0.4, seed=1))                     # 0: inside the last slab
+    inits.append(np.eye(4))
+    e = edges[1]
+    scans.append(scan_from(np.abs(x - e) < 0.6, seed=2))                                  # 1: straddles slabs 0 | 1
+    inits.append(np.eye(4))
+    scans.append(scan_from(np.ones(len(ds), bool), n=2500, seed=3))                       # 2: the whole map
+    inits.append(np.eye(4))
+    scans.append(scan_from(np.abs(x - inner[0]) < 0.4, seed=4))                           # 3: inside slab 0
+    inits.append(np.eye(4))
+    T_move = synth.make_T((0.8, 0.0, 0.0), (0.0, 0.0, 0.0))                               # 4: lies wholly inside slab 0 as given ...
+    scans.append(scan_from(np.abs(x - e) < 0.35, T=T_move, seed=5))
+    inits.append(synth.make_T((0.78, 0.01, 0.0), (0.0, 0.0, 0.0)))                        # ... and is moved across the edge by its prior
+    assert scans[-1][:, 0].max() < e - 0.3
+    n = min(len(s) for s in scans)
+    scans = np.stack([s[:n] for s in scans])
+    return ds, edges, scans, np.stack(inits)
+
+
+def worker_routed(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from slam_sensor_fusion_amd import api, sharded, synth
+    ds, edges, scans, inits = routed_world(orc, synth, world)
+    keep = sharded.slab_select(ds, edges, rank, halo=MAX_DIST + NORMAL_RADIUS + 0.25)
+    # every rank's normals come from the full map here, so that a local registration can be compared bit for bit in
+    # its record sums with the unsharded one (on the GPU the halo makes the slab's own normals identical in the core)
+    normals_full, _ = orc.normals_radius(ds, NORMAL_RADIUS)
+    local_map, local_nrm = ds[keep], normals_full[keep]
+    groups_by_range = {rg: dist.new_group(list(range(rg[0], rg[1] + 1))) for rg in sharded.contiguous_ranges(world)}   # same order on every rank
+    log = []
+    reg = sharded.RoutedRegistration(rank, world, edges, api.shard_route,
+                                     make_local=lambda: NumpyRoutedIcp(orc, local_map, local_nrm, log),
+                                     make_sharded=lambda lo, hi: (NumpyRoutedIcp(orc, local_map, local_nrm, log), groups_by_range[(lo, hi)]),
+                                     margin=0.3)
+    groups = reg.set_source_batch(scans, inits)
+    res = reg.align("p2plane")
+    np.save(os.path.join(out_dir, "groups_%d.npy" % rank), np.array([[a, e, b] for (a, e), ids in groups.items() for b in ids]))
+    for b, r in res.items():
+        np.save(os.path.join(out_dir, "T_%d_%d.npy" % (b, rank)), r["T64"])
+        np.save(os.path.join(out_dir, "n_%d_%d.npy" % (b, rank)), np.array([r["n_corr"], r["iterations"]]))
+    np.save(os.path.join(out_dir, "coll_%d.npy" % rank), np.array([len([1 for kind, _ in log if kind == "allreduce"]), len([1 for kind, _ in log if kind == "local"])]))
+    # a rank never issues a collective on a group it is not part of
+    for kind, who in log:
+        assert kind != "allreduce" or rank in who
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_routed_registration_only_spanning_scans_use_collectives(orc, synth, tmp_path, world):
+    mp.spawn(worker_routed, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    ds, edges, scans, inits = routed_world(orc, synth, world)
+    normals, _ = orc.normals_radius(ds, NORMAL_RADIUS)
+    plan = np.load(tmp_path / "groups_0.npy")
+    for r in range(1, world):
+        assert np.array_equal(plan, np.load(tmp_path / ("groups_%d.npy" % r)))        # every rank computes the same routing
+    ranges = {int(b): (int(a), int(e)) for a, e, b in plan}
+    assert ranges[0] == (world - 1, world - 1) and ranges[3] == (0, 0)                 # single-slab scans: one rank, no collective
+    assert ranges[1] == (0, 1) and ranges[2] == (0, world - 1) and ranges[4] == (0, 1)
+    for b in range(len(scans)):
+        a, e = ranges[b]
+        ref = orc.icp_p2plane(scans[b], ds, normals, inits[b], MAX_DIST, ITERS)
+        Ts = []
+        for r in range(world):
+            f = tmp_path / ("T_%d_%d.npy" % (b, r))
+            assert f.exists() == (a <= r <= e), (b, r)                                 # only the ranks of the scan's range take part
+            if f.exists():
+                Ts.append(np.load(f))
+                n = np.load(tmp_path / ("n_%d_%d.npy" % (b, r)))
+                assert n[0] == ref["n_corr"] and n[1] == ITERS                         # every query owned exactly once
+        for T in Ts[1:]:
+            assert np.array_equal(T, Ts[0])                                            # identical solve on every participating rank
+        dt, dr = synth.pose_error(Ts[0], ref["T"])
+        assert dt < 1e-9 and dr < 1e-9, (b, dt, dr)
+    # collectives: rank r joins ITERS all-reduces per multi-slab group it belongs to, none for its local scans
+    multi = sorted(set(rg for rg in ranges.values() if rg[0] != rg[1]))
+    for r in range(world):
+        coll = np.load(tmp_path / ("coll_%d.npy" % r))
+        assert coll[0] == ITERS * sum(1 for a, e in multi if a <= r <= e)
+        assert coll[1] == len(set(rg for rg in ranges.values() if rg == (r, r)))
