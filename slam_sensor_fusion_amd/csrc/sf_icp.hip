@@ -27,8 +27,7 @@
 // active return immediately, so the launch list is static and graph-capturable.
 #include "sf_common.hpp"
 #include "sf_nn.hpp"
-
-#include <rocprim/rocprim.hpp>
+#include "sf_order.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -665,38 +664,68 @@ __device__ __forceinline__ uint64_t order_cell(const SfGrid &g, int cx, int cy, 
     return ((yb * (uint64_t)g.dim[2] + (uint64_t)cz) * ORDER_YBLK + yi) * (uint64_t)g.dim[0] + (uint64_t)cx;
 }
 
-__global__ void k_query_keys(SfGrid g, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n, int64_t total,
-                             const IcpState *__restrict__ st, int shift, uint32_t nkeys, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
-{
-    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= total) return;
-    const int b = (int)(o / n);
-    const IcpState *S = st + b;
-    const double x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
-    const float qx = (float)(S->T[0] * x0 + S->T[1] * y0 + S->T[2] * z0 + S->T[3]);
-    const float qy = (float)(S->T[4] * x0 + S->T[5] * y0 + S->T[6] * z0 + S->T[7]);
-    const float qz = (float)(S->T[8] * x0 + S->T[9] * y0 + S->T[10] * z0 + S->T[11]);
-    uint32_t key = nkeys - 1; // non-finite queries go to the end of their scan
-    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) {
+// 10-bit bucket key of global query o (scan o / n): its cell under the scan's current pose, in walk order
+struct CellKeyFn {
+    SfGrid g;
+    const float *x, *y, *z;
+    const IcpState *st;
+    int n, shift;
+    // The key is a locality hint, not a result: float32 arithmetic (the pose rounded once per workgroup) puts a
+    // query that sits on a bucket border into one of the two buckets, deterministically.
+    struct Point { float x, y, z; };
+    struct Pose { float T[12]; };
+    __device__ __forceinline__ Pose prepare(int b) const
+    {
+        Pose P;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) P.T[k] = (float)st[b].T[k];
+        return P;
+    }
+    __device__ __forceinline__ Point load(uint32_t o) const { return Point{x[o], y[o], z[o]}; }
+    __device__ __forceinline__ uint32_t key(const Pose &P, const Point &p) const
+    {
+        const float qx = fmaf(P.T[0], p.x, fmaf(P.T[1], p.y, fmaf(P.T[2], p.z, P.T[3])));
+        const float qy = fmaf(P.T[4], p.x, fmaf(P.T[5], p.y, fmaf(P.T[6], p.z, P.T[7])));
+        const float qz = fmaf(P.T[8], p.x, fmaf(P.T[9], p.y, fmaf(P.T[10], p.z, P.T[11])));
+        if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return sf::ORD_KEY_NONE; // non-finite queries go to the end of their scan
         const int cx = (int)fminf(fmaxf(floorf((qx - g.org[0]) * g.inv_h), 0.0f), (float)(g.dim[0] - 1));
         const int cy = (int)fminf(fmaxf(floorf((qy - g.org[1]) * g.inv_h), 0.0f), (float)(g.dim[1] - 1));
         const int cz = (int)fminf(fmaxf(floorf((qz - g.org[2]) * g.inv_h), 0.0f), (float)(g.dim[2] - 1));
-        const uint64_t cell = order_cell(g, cx, cy, cz);
-        key = (uint32_t)(cell >> shift);
+        const uint64_t key = order_cell(g, cx, cy, cz) >> shift;
+        return (uint32_t)(key < (uint64_t)(sf::ORD_KEY_NONE - 1u) ? key : (uint64_t)(sf::ORD_KEY_NONE - 1u));
     }
-    keys[o] = (uint32_t)b * nkeys + key;
-    idx[o] = (uint32_t)o;
+};
+
+__global__ __launch_bounds__(sf::ORD_BLK) void k_order_hist(sf::OrderSrc s, CellKeyFn kf, uint16_t *__restrict__ keys, uint32_t *__restrict__ counts)
+{
+    sf::order_hist_body(s, kf, keys, counts);
 }
 
-__global__ void k_gather_queries(const float4 *__restrict__ rec, const uint32_t *__restrict__ idx, int64_t total, float *__restrict__ Xx, float *__restrict__ Xy,
-                                 float *__restrict__ Xz)
+__global__ __launch_bounds__(sf::ORD_BLK) void k_order_scatter(sf::OrderSrc s, const uint16_t *__restrict__ keys, const uint32_t *__restrict__ starts, uint32_t *__restrict__ out)
 {
-    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= total) return;
-    const float4 v = rec[idx[o]];
-    Xx[o] = v.x;
-    Xy[o] = v.y;
-    Xz[o] = v.z;
+    sf::order_scatter_body(s, keys, starts, out);
+}
+
+// the ordered ids read coalesced, the queries' float4 records gathered (four in flight per lane), the cell-ordered
+// SoA arrays written coalesced
+constexpr int GATHER_PER_LANE = 4;
+__global__ __launch_bounds__(256) void k_order_gather(const float4 *__restrict__ rec, const uint32_t *__restrict__ idx, int64_t total, float *__restrict__ Xx,
+                                                      float *__restrict__ Xy, float *__restrict__ Xz)
+{
+    const int64_t base = (int64_t)blockIdx.x * (256 * GATHER_PER_LANE) + threadIdx.x;
+    uint32_t o[GATHER_PER_LANE];
+    float4 v[GATHER_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < GATHER_PER_LANE; ++k) o[k] = base + 256 * k < total ? idx[base + 256 * k] : 0u;
+#pragma unroll
+    for (int k = 0; k < GATHER_PER_LANE; ++k) v[k] = rec[o[k]];
+#pragma unroll
+    for (int k = 0; k < GATHER_PER_LANE; ++k)
+        if (base + 256 * k < total) {
+            Xx[base + 256 * k] = v[k].x;
+            Xy[base + 256 * k] = v[k].y;
+            Xz[base + 256 * k] = v[k].z;
+        }
 }
 
 // ------------------------------------------------------------------ sharded path: owned queries
@@ -809,30 +838,6 @@ __global__ __launch_bounds__(BLK) void k_own_scatter(const float *__restrict__ X
     uint32_t off = own_off[b] + blk_off[(size_t)b * nblocks + blockIdx.x];
     for (int k = 0; k < wv; ++k) off += wcnt[k];
     own_idx[off + own_lane_rank(bal)] = (uint32_t)((size_t)b * n + i);
-}
-
-// sort keys of the owned queries: scan id, then map cell under the current pose (cf. k_query_keys)
-__global__ void k_own_keys(SfGrid g, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
-                           const uint32_t *__restrict__ own_idx, int64_t total, const IcpState *__restrict__ st, int shift, uint32_t nkeys, uint32_t *__restrict__ keys)
-{
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const uint32_t o = own_idx[e];
-    const int b = (int)(o / (uint32_t)n);
-    const IcpState *S = st + b;
-    const double x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
-    const float qx = (float)(S->T[0] * x0 + S->T[1] * y0 + S->T[2] * z0 + S->T[3]);
-    const float qy = (float)(S->T[4] * x0 + S->T[5] * y0 + S->T[6] * z0 + S->T[7]);
-    const float qz = (float)(S->T[8] * x0 + S->T[9] * y0 + S->T[10] * z0 + S->T[11]);
-    uint32_t key = nkeys - 1;
-    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) {
-        const int cx = (int)fminf(fmaxf(floorf((qx - g.org[0]) * g.inv_h), 0.0f), (float)(g.dim[0] - 1));
-        const int cy = (int)fminf(fmaxf(floorf((qy - g.org[1]) * g.inv_h), 0.0f), (float)(g.dim[1] - 1));
-        const int cz = (int)fminf(fmaxf(floorf((qz - g.org[2]) * g.inv_h), 0.0f), (float)(g.dim[2] - 1));
-        const uint64_t cell = order_cell(g, cx, cy, cz);
-        key = (uint32_t)(cell >> shift);
-    }
-    keys[e] = (uint32_t)b * nkeys + key;
 }
 
 // the pose the owned arrays were built at
@@ -1205,19 +1210,14 @@ const float *src(sf_icp *icp, int axis)
 // scans, 20 iterations: 1 scan in flight +1.5 % (break-even), 2: +8 %, 4: +32 %, 32: +65 %
 constexpr int64_t ORDER_AUTO_MIN_QUERIES = 300000;
 
-// sort key = scan id, then the map cell (x fastest) shifted down to 24 key bits in all: a finer
-// order gains nothing, a coarser one loses (measured 12..30 bits)
-void order_key_layout(const SfGrid &g, int batch, int *shift, uint32_t *nkeys, int *bits)
+// key = position of the query's cell in the walk order (order_cell), shifted down to the 20 bits the sort takes
+int order_key_shift(const SfGrid &g)
 {
     const uint64_t ny_pad = ((uint64_t)g.dim[1] + ORDER_YBLK - 1) / ORDER_YBLK * ORDER_YBLK; // order_cell pads y to whole blocks
     const uint64_t ncell = (uint64_t)g.dim[0] * ny_pad * (uint64_t)g.dim[2];
-    int bbits = 0, cbits = 0;
-    while ((1u << bbits) < (unsigned)batch) ++bbits;
+    int cbits = 0;
     while (cbits < 63 && (1ull << cbits) < ncell) ++cbits;
-    *shift = std::max(0, cbits + bbits - 24);
-    *nkeys = (uint32_t)((ncell - 1) >> *shift) + 1;
-    *bits = 0;
-    while (*bits < 32 && (1ull << *bits) < (uint64_t)*nkeys * (uint64_t)batch) ++*bits;
+    return std::max(0, cbits - sf::ORD_KEY_BITS);
 }
 
 // neighbour reuse starts empty at every alignment (a zero bound certifies nothing)
@@ -1231,36 +1231,47 @@ int reuse_reset(sf_icp *icp, int64_t count)
     return SF_OK;
 }
 
+// the segmented stable bucket sort of sf_order.hpp: nseg segments (uniform: nseg scans of icp->n queries; sharded: the
+// owned-query candidates of each scan, seg_off / src_idx on the device), `longest` = the longest segment
+int run_order_sort(sf_icp *icp, int nseg, int64_t longest, int64_t total, const uint32_t *seg_off, const uint32_t *src_idx)
+{
+    const SfGrid &g = icp->map->grid;
+    const int64_t all = icp->n * icp->batch;
+    sf::OrderSrc src;
+    src.src_idx = src_idx;
+    src.seg_off = seg_off;
+    src.n = (int)icp->n;
+    src.tiles = (int)std::max<int64_t>(1, sf::div_up(longest, sf::ORD_TILE));
+    CellKeyFn kf;
+    kf.g = g;
+    kf.x = soa(icp->X0, all, 0); kf.y = soa(icp->X0, all, 1); kf.z = soa(icp->X0, all, 2);
+    kf.st = icp->state.as<IcpState>();
+    kf.shift = order_key_shift(g);
+    const size_t cap = (size_t)std::max<int64_t>(total, 1);
+    SF_TRY(icp->Xq.reserve(sizeof(float) * 3 * cap));
+    SF_TRY(icp->qkeys.reserve(sizeof(uint16_t) * cap));                                                      // bucket key of every element
+    SF_TRY(icp->qkeys2.reserve(sizeof(uint32_t) * (size_t)nseg * (size_t)(src.tiles + 1) * sf::ORD_BINS));  // per-tile bucket counts / starts
+    SF_TRY(icp->qidx.reserve(sizeof(uint32_t) * cap));                                                       // ordered query ids
+    uint16_t *keys = icp->qkeys.as<uint16_t>();
+    uint32_t *counts = icp->qkeys2.as<uint32_t>(), *ordered = icp->qidx.as<uint32_t>();
+    hipStream_t s = icp->ctx->stream;
+    const dim3 grid((unsigned)src.tiles, (unsigned)nseg), blk(sf::ORD_BLK);
+    hipLaunchKernelGGL(k_order_hist, grid, blk, 0, s, src, kf, keys, counts);
+    hipLaunchKernelGGL(sf::k_order_scan, dim3((unsigned)nseg), dim3(sf::ORD_BINS), 0, s, counts, src.tiles);
+    hipLaunchKernelGGL(k_order_scatter, grid, blk, 0, s, src, keys, counts, ordered);
+    hipLaunchKernelGGL(k_order_gather, dim3(nblk(total, 256 * GATHER_PER_LANE)), dim3(256), 0, s, icp->X0r.as<float4>(), ordered, total, soa(icp->Xq, total, 0),
+                       soa(icp->Xq, total, 1), soa(icp->Xq, total, 2));
+    SF_HIP(hipGetLastError());
+    return SF_OK;
+}
+
 int order_queries(sf_icp *icp, int mode)
 {
     const int64_t total = icp->n * icp->batch;
     const bool want = icp->order == SF_ORDER_CELL || (icp->order == SF_ORDER_AUTO && total >= ORDER_AUTO_MIN_QUERIES);
     icp->ordered = false;
     if (!want || mode == SF_ICP_REF_CPP || total == 0 || icp->map->grid.n == 0) return SF_OK;
-    const SfGrid &g = icp->map->grid;
-    int shift, bits;
-    uint32_t nkeys;
-    order_key_layout(g, icp->batch, &shift, &nkeys, &bits);
-    const size_t nb = sizeof(uint32_t) * (size_t)total;
-    SF_TRY(icp->Xq.reserve(sizeof(float) * 3 * (size_t)total));
-    SF_TRY(icp->qkeys.reserve(nb));
-    SF_TRY(icp->qkeys2.reserve(nb));
-    SF_TRY(icp->qidx.reserve(nb));
-    SF_TRY(icp->qidx2.reserve(nb));
-    hipStream_t s = icp->ctx->stream;
-    hipLaunchKernelGGL(k_query_keys, dim3(nblk(total)), dim3(256), 0, s, g, soa(icp->X0, total, 0), soa(icp->X0, total, 1), soa(icp->X0, total, 2), (int)icp->n, total,
-                       icp->state.as<IcpState>(), shift, nkeys, icp->qkeys.as<uint32_t>(), icp->qidx.as<uint32_t>());
-    size_t tmp = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, icp->qkeys.as<uint32_t>(), icp->qkeys2.as<uint32_t>(), icp->qidx.as<uint32_t>(), icp->qidx2.as<uint32_t>(),
-                                             (size_t)total, 0, bits, s);
-    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs(size): %s", hipGetErrorString(e));
-    SF_TRY(sf::ensure_scratch(icp->ctx, tmp));
-    e = rocprim::radix_sort_pairs(icp->ctx->scratch.p, tmp, icp->qkeys.as<uint32_t>(), icp->qkeys2.as<uint32_t>(), icp->qidx.as<uint32_t>(), icp->qidx2.as<uint32_t>(),
-                                  (size_t)total, 0, bits, s);
-    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_gather_queries, dim3(nblk(total)), dim3(256), 0, s, icp->X0r.as<float4>(),
-                       icp->qidx2.as<uint32_t>(), total, soa(icp->Xq, total, 0), soa(icp->Xq, total, 1), soa(icp->Xq, total, 2));
-    SF_HIP(hipGetLastError());
+    SF_TRY(run_order_sort(icp, icp->batch, icp->n, total, nullptr, nullptr));
     icp->ordered = true;
     return SF_OK;
 }
@@ -1751,31 +1762,13 @@ int shard_build(sf_icp *icp, bool resume)
     SF_HIP(hipMemcpyAsync(icp->own_off.p, icp->h_own.data(), sizeof(uint32_t) * (size_t)(B + 1), hipMemcpyHostToDevice, s));
     const size_t cap = (size_t)std::max<int64_t>(own, 1);
     SF_TRY(icp->own_idx.reserve(sizeof(uint32_t) * cap));
-    SF_TRY(icp->qkeys.reserve(sizeof(uint32_t) * cap));
-    SF_TRY(icp->qkeys2.reserve(sizeof(uint32_t) * cap));
-    SF_TRY(icp->qidx2.reserve(sizeof(uint32_t) * cap));
     SF_TRY(icp->Xq.reserve(sizeof(float) * 3 * cap));
     if (own > 0) {
         hipLaunchKernelGGL(k_own_scatter, grid, dim3(BLK), 0, s, X, Y, Z, n, st, icp->xlo, icp->xhi, icp->own_margin, icp->own_blk.as<uint32_t>(), nbf, icp->own_off.as<uint32_t>(),
                            icp->own_idx.as<uint32_t>());
-        const SfGrid &g = icp->map->grid;
-        const uint32_t *order = icp->own_idx.as<uint32_t>(); // as compacted (original order) when the map is empty
-        if (g.n > 0) {
-            int shift, bits;
-            uint32_t nkeys;
-            order_key_layout(g, B, &shift, &nkeys, &bits);
-            hipLaunchKernelGGL(k_own_keys, dim3(nblk(own)), dim3(256), 0, s, g, X, Y, Z, n, icp->own_idx.as<uint32_t>(), own, st, shift, nkeys, icp->qkeys.as<uint32_t>());
-            size_t tmp = 0;
-            hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, icp->qkeys.as<uint32_t>(), icp->qkeys2.as<uint32_t>(), icp->own_idx.as<uint32_t>(),
-                                                     icp->qidx2.as<uint32_t>(), (size_t)own, 0, bits, s);
-            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs(size): %s", hipGetErrorString(e));
-            SF_TRY(sf::ensure_scratch(icp->ctx, tmp));
-            e = rocprim::radix_sort_pairs(icp->ctx->scratch.p, tmp, icp->qkeys.as<uint32_t>(), icp->qkeys2.as<uint32_t>(), icp->own_idx.as<uint32_t>(),
-                                          icp->qidx2.as<uint32_t>(), (size_t)own, 0, bits, s);
-            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs: %s", hipGetErrorString(e));
-            order = icp->qidx2.as<uint32_t>();
-        }
-        hipLaunchKernelGGL(k_gather_queries, dim3(nblk(own)), dim3(256), 0, s, icp->X0r.as<float4>(), order, own, soa(icp->Xq, own, 0), soa(icp->Xq, own, 1), soa(icp->Xq, own, 2));
+        // cell-order every scan's candidates and gather them into the compact arrays (segments = own_off, elements ->
+        // global query ids = own_idx); with an empty map every key is equal and the stable sort keeps the compacted order
+        SF_TRY(run_order_sort(icp, B, (int64_t)maxc, own, icp->own_off.as<uint32_t>(), icp->own_idx.as<uint32_t>()));
     }
     hipLaunchKernelGGL(k_own_mark, dim3(nblk(B, 64)), dim3(64), 0, s, st, B);
     SF_HIP(hipGetLastError());
