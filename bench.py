@@ -2,22 +2,27 @@
 """bench.py — scan-to-map registration throughput on MI355X.
 
 Metric (BASELINE.json): scans/s and ms/ICP-iteration, 200k-point scans vs a 10M-point map
-(uniform-random synthetic), 20 point-to-plane ICP iterations per scan,
-exact NN every iteration.  A "step" = one batch of `--batch` scans pushed through the whole
-ICP (20 x [fused transform+NN+accumulate kernel, reduce+solve kernel]) with scans and map
-already resident in HBM.
+(uniform-random synthetic).  A "step" = one batch of `--batch` scans pushed through the
+whole ICP with scans and map already resident in HBM.  `--mode`:
+  p2plane  (default; the north_star's hot path) 20 Gauss-Newton point-to-plane iterations, NN every iteration
+  o3d_p2p  the Python reference's registration_icp (localization_node.py:233-237): 30 point-to-point iterations
+  ref_cpp  the C++ reference's ICPPointToPoint::calculateAlignment (icp_point_to_point.cpp:185-254) with the node's
+           parameters 0.5 / 10 / 0.05 / 1e-5 (localization_node.cpp:24-28): lazy re-search, float32 point updates
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: the map is tile-sharded along x (equal-count slabs + halo); `--batch` scans are in flight
-PER GPU (N x 32 in all), every rank holds the whole scan batch, accumulates only the queries
-that fall in its slab (1/N of every scan), and the 30-double normal-equation records are
-all-reduced over RCCL once per ICP iteration; `--pipeline 2` steps the batch as two
-halves on two streams so that one half's all-reduce (latency-bound) overlaps the other half's
-search.  Work per GPU is fixed as N grows => "scaling": "weak"; `value` = all scans of all ranks'
-common batch / wall time.
+N > 1: the map is tile-sharded along x (equal-count slabs + halo).  Default (`--scan-kind whole`, BASELINE's
+synthetic scans: points drawn from the WHOLE map) every scan spans every tile, so every rank owns 1/N of each
+scan's queries and the 30-double normal-equation records are all-reduced over RCCL once per ICP iteration; the whole
+iteration loop incl. the collective is enqueued from the C side (sf_icp_align_sharded; falls back to
+torch.distributed stepping if the C-side communicator cannot be created).  `--scan-kind local` draws every scan
+from a 10 m neighbourhood (what a sensor sees; the reference crops to 10 m, localization_node.cpp:296): scans are
+routed to the tiles they touch, one-tile scans are registered by one rank alone with no collective, spanning scans
+all-reduce on a communicator of just their ranks (sharded.RoutedRegistration).
+`--scaling weak` (default): `--batch` scans in flight PER GPU (N x batch in all); `strong`: `--batch` in all.
+`value` = all scans of the common batch / wall time (max over ranks).
 """
 import argparse
 import json
@@ -33,6 +38,9 @@ sys.path.insert(0, ROOT)
 A_NN_P2PLANE = 754.0   # algorithmic bytes per query-iteration, point-to-plane
 A_NN_P2P = 742.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-5          # north_star: pose within 1e-4 m / 1e-5 rad of the reference CPU path
+MODE_DEFAULT_ITERS = {"p2plane": 20, "o3d_p2p": 30, "ref_cpp": 10}
+N_SIMD, CLOCK_GHZ = 1024, 2.4                   # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md max clock
 
 
 def parse():
@@ -42,24 +50,33 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--map-points", type=int, default=10_000_000)
     ap.add_argument("--scan-points", type=int, default=200_000)
-    ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=32, help="scans registered concurrently per step, per GPU")
-    ap.add_argument("--pipeline", type=int, default=1,
-                    help="sharded runs: step the batch as this many parts on separate streams so that one part's all-reduce overlaps the "
-                         "next part's search (sharded.PipelinedShardedIcp).  With one rank 2 parts cost 17 %% (smaller kernels, twice the "
-                         "host calls); whether it pays with 8 ranks depends on the RCCL latency, to be decided on a multi-GPU measurement")
+    ap.add_argument("--iters", type=int, default=0, help="0 = the mode's default (p2plane 20, o3d_p2p 30, ref_cpp 10)")
+    ap.add_argument("--batch", type=int, default=32, help="scans registered concurrently per step (per GPU with --scaling weak)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scan-kind", default="whole", choices=["whole", "local"],
+                    help="whole: BASELINE's scans (points drawn from the whole map); local: a 10 m neighbourhood per scan, routed to the tiles it touches")
     ap.add_argument("--force-dist", action="store_true",
-                    help="run the sharded stepping path + collective even with one rank (rehearses the RCCL plumbing on one GPU)")
-    ap.add_argument("--mode", default="p2plane", choices=["p2plane", "o3d_p2p"])
+                    help="run the sharded path + collective even with one rank (rehearses the RCCL plumbing on one GPU)")
+    ap.add_argument("--collective", default="c", choices=["c", "torch"],
+                    help="c: the whole sharded iteration loop incl. RCCL from the C side (sf_icp_align_sharded); torch: step_begin / dist.all_reduce / step_end from Python")
+    ap.add_argument("--mode", default="p2plane", choices=["p2plane", "o3d_p2p", "ref_cpp"])
     ap.add_argument("--cell", type=float, default=0.25)
     ap.add_argument("--query-order", default="auto", choices=["auto", "as_given", "cell"], help="sf_icp_set_query_order")
     ap.add_argument("--no-nn-reuse", action="store_true", help="sf_icp_set_nn_reuse(0): search every query in every iteration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (no-reuse throughput, upload-inclusive rate, single-scan latency)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--cpu-baseline-iters", type=int, default=20)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL, default); gloo only to rehearse the N>1 path with several ranks on ONE GPU")
+                    help="nccl (= RCCL, default); gloo only to rehearse the N>1 path with several ranks on ONE GPU (forces --collective torch)")
     return ap.parse_args()
+
+
+def local_scan(synth, map_sorted_x, center, n_points, scan_id):
+    """A scan a sensor at `center` sees: n points of the map within 10 m (localization_node.cpp:296), noise and T_true as make_scan."""
+    lo, hi = np.searchsorted(map_sorted_x[:, 0], [center[0] - 10.0, center[0] + 10.0])
+    near = map_sorted_x[lo:hi]
+    near = near[((near[:, :2] - center[:2]) ** 2).sum(1) < 100.0]
+    return synth.make_scan(near, n_points, scan_id=scan_id)[0]
 
 
 def main():
@@ -74,8 +91,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); torch.cuda.is_available() is False")
     device = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
+    iters = args.iters or MODE_DEFAULT_ITERS[args.mode]
     dist = None
     sharded_run = world > 1 or args.force_dist
+    if sharded_run and args.mode == "ref_cpp":
+        raise SystemExit("the sharded path registers with p2plane / o3d_p2p (sf_icp_step_begin); ref_cpp runs unsharded")
     if sharded_run:
         import torch.distributed as dist
         if world == 1:
@@ -87,6 +107,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo")
+            args.collective = "torch"
     stream = torch.cuda.Stream()
     ctx = api.Context(device, stream.cuda_stream)
 
@@ -105,48 +126,128 @@ def main():
         keep = sharded.slab_select(map_ds, edges, rank, halo=max_dist + normal_radius + args.cell)
         cloud = api.Cloud(ctx, map_ds[keep])
     mp = api.Map(ctx, cloud, args.cell)
-    mp.estimate_normals(normal_radius)
-    B = args.batch * world                        # weak scaling: --batch scans in flight per GPU
-    scans = np.stack([synth.make_scan(map_ds, args.scan_points, scan_id=rank * 0 + b)[0] for b in range(B)])
+    if args.mode == "p2plane":
+        mp.estimate_normals(normal_radius)
+    B = args.batch * world if args.scaling == "weak" else args.batch
+    if args.scan_kind == "whole":
+        scans = np.stack([synth.make_scan(map_ds, args.scan_points, scan_id=b)[0] for b in range(B)])
+    else:
+        msx = map_ds[np.argsort(map_ds[:, 0], kind="stable")]
+        rng = np.random.Generator(np.random.PCG64(synth.SCAN_SEED - 1))
+        L = float(np.sqrt(args.map_points / synth.DENSITY))
+        centers = np.c_[rng.uniform(-L / 2 + 10, L / 2 - 10, B), rng.uniform(-L / 2 + 10, L / 2 - 10, B), np.zeros(B)]
+        scans = [local_scan(synth, msx, centers[b], args.scan_points, b) for b in range(B)]
+        n_min = min(len(s) for s in scans)
+        scans = np.stack([s[:n_min] for s in scans])
+        del msx
     n_scan = scans.shape[1]
-    parts = max(1, min(args.pipeline, B)) if sharded_run else 1
-    while B % parts:
-        parts -= 1
-    streams = [stream] + [torch.cuda.Stream() for _ in range(parts - 1)]
-    ctxs = [ctx] + [api.Context(device, st.cuda_stream) for st in streams[1:]]
-    icps, xbufs = [], []
-    for h in range(parts):
-        part = api.Icp(ctxs[h], max_dist, args.iters, 0.05, 1e-5)
-        part.set_target(mp)                                # the map index is shared (read-only) by the parts
-        part.set_source_batch(scans[h * (B // parts):(h + 1) * (B // parts)])
-        part.set_initial_batch(None)
-        part.use_graph(not args.no_graph)
-        part.set_query_order(args.query_order)
-        part.set_nn_reuse(not args.no_nn_reuse)
-        icps.append(part)
-    icp = icps[0]
-    drv = None
-    if sharded_run:
-        lo, hi = float(edges[rank]), float(edges[rank + 1])
-        pairs = []
-        for h, part in enumerate(icps):
-            part.set_shard(max(lo, -1e30), min(hi, 1e30))   # finite bounds keep the sharded code path even for one rank
-            xb = torch.zeros((B // parts) * 32, dtype=torch.float64, device="cuda")
-            part.set_exchange_buffer(xb.data_ptr(), xb.numel() * 8)
-            xbufs.append(xb)
 
-            def allreduce(xb=xb, st=streams[h]):
-                with torch.cuda.stream(st):
-                    dist.all_reduce(xb)
-            pairs.append((part, allreduce))
-        drv = sharded.PipelinedShardedIcp(pairs, args.mode, args.iters)
+    def new_icp(context=ctx):
+        icp = api.Icp(context, max_dist, iters, 0.05, 1e-5)
+        icp.set_target(mp)
+        icp.use_graph(not args.no_graph)
+        icp.set_query_order(args.query_order)
+        icp.set_nn_reuse(not args.no_nn_reuse)
+        return icp
+
+    # ---------------- the registration driver of this rank
+    routed, comm_kind, icp, comm, xbuf = None, "none", None, None, None
+    my_scans = list(range(B))                     # scan ids this rank takes part in
+    if not sharded_run:
+        icp = new_icp()
+        icp.set_source_batch(scans)
+        icp.set_initial_batch(None)
+    else:
+        def make_comm(lo, hi):
+            """C-side RCCL communicator of the ranks lo..hi (every member calls this in the same order)."""
+            ident = [api.Comm.unique_id() if rank == lo else None]
+            dist.broadcast_object_list(ident, src=lo, group=groups[(lo, hi)] if (lo, hi) in groups else None)
+            return api.Comm(ctx, hi - lo + 1, rank - lo, ident[0])
+
+        groups = {}
+        if args.scan_kind == "local" and world > 1:   # torch sub-groups: rendezvous for the ids (and the torch fallback's collectives)
+            groups = {rg: dist.new_group(list(range(rg[0], rg[1] + 1))) for rg in sharded.contiguous_ranges(world) if rg != (0, world - 1)}
+        ok_c = 1
+        if args.collective == "c":
+            try:
+                world_comm = make_comm(0, world - 1)
+            except Exception as e:                   # noqa: BLE001 -- any failure: every rank must take the same branch
+                print("rank %d: C-side RCCL communicator failed (%s); falling back to torch.distributed stepping" % (rank, e), file=sys.stderr)
+                ok_c, world_comm = 0, None
+            flag = torch.tensor([ok_c], device="cuda" if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok_c = int(flag.item())
+        else:
+            ok_c, world_comm = 0, None
+        comm_kind = "rccl from the C side (sf_icp_align_sharded)" if ok_c else "torch.distributed all_reduce per iteration (Python stepping)"
+
+        class TorchSharded:
+            """Fallback: the stepping API + dist.all_reduce from Python (round-1 path), same interface as api.Icp.align_sharded."""
+
+            def __init__(self, icp_, group):
+                self.icp, self.group, self.resumes = icp_, group, 0
+
+            def __getattr__(self, name):
+                return getattr(self.icp, name)
+
+            def set_source_batch(self, s):
+                self.icp.set_source_batch(s)
+                self.xb = torch.zeros(self.icp.batch * 32, dtype=torch.float64, device="cuda")
+                self.icp.set_exchange_buffer(self.xb.data_ptr(), self.xb.numel() * 8)
+
+            def align_sharded(self, mode, comm_):
+                def allreduce():
+                    with torch.cuda.stream(stream):
+                        dist.all_reduce(self.xb, group=self.group)
+                drv = sharded.ShardedIcp(self.icp, mode, iters, allreduce)
+                res = drv.align()
+                self.resumes = drv.resumes
+                return res
+
+        comms = {(0, world - 1): world_comm}
+
+        def make_sharded(lo, hi):
+            if ok_c:
+                if (lo, hi) not in comms:
+                    comms[(lo, hi)] = make_comm(lo, hi)
+                return new_icp(), comms[(lo, hi)]
+            return TorchSharded(new_icp(), groups.get((lo, hi))), None
+
+        ctx_local = api.Context(device, torch.cuda.Stream().cuda_stream) if args.scan_kind == "local" else ctx
+        routed = sharded.RoutedRegistration(rank, world, edges, api.shard_route, make_local=lambda: new_icp(ctx_local), make_sharded=make_sharded, margin=1.0)
+        if ok_c and args.scan_kind == "local":      # communicators must be created in the same order on every rank: plan first
+            lo_, hi_ = api.shard_route(scans, None, edges, 1.0)
+            for (a, e) in sharded.plan_groups(lo_, hi_):
+                if a != e and (a, e) not in comms:
+                    if a <= rank <= e:
+                        comms[(a, e)] = make_comm(a, e)
+        if world == 1:                              # --force-dist: one rank, the sharded path on the whole batch (routing would call it local)
+            class OneRank:
+                groups, resumes = {(0, 0): list(range(B))}, 0
+
+                def __init__(self):
+                    self.icp, self.comm = make_sharded(0, 0)
+                    self.icp.set_shard(-1e30, 1e30)
+                    self.icp.set_source_batch(scans)
+                    self.icp.set_initial_batch(None)
+
+                def align(self, mode):
+                    res = self.icp.align_sharded(mode, self.comm)
+                    self.resumes = int(getattr(self.icp, "resumes", 0))
+                    return dict(enumerate(res))
+            routed = OneRank()
+        else:
+            plan = routed.set_source_batch(scans, None)
+            my_scans = sorted(b for (a, e), ids in plan.items() if a <= rank <= e for b in ids)
     setup_s = time.time() - t_setup
 
+    results_box = {}
+
     def step():
-        if drv is None:
+        if routed is None:
             icp.align_batch_async(args.mode)
         else:
-            drv.align()       # blocking: the driver checks for scans that must be resumed (sharded.py)
+            results_box["r"] = routed.align(args.mode)    # blocking per group: resumes are decided on fetched states
 
     def barrier():
         if dist is not None:
@@ -165,64 +266,149 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    results = [r for part in icps for r in part.fetch_results()]
+    if routed is None:
+        results = dict(enumerate(icp.fetch_results()))
+    else:
+        results = results_box["r"]
 
-    # ---------------- correctness of what was timed: every scan must recover T_true
-    terr = max(synth.pose_error(r["T64"], synth.t_true())[0] for r in results)
-    rerr = max(synth.pose_error(r["T64"], synth.t_true())[1] for r in results)
-    ok = all(r["iterations"] == args.iters or args.mode != "p2plane" for r in results) and terr < 5e-3
+    # ---------------- correctness of what was timed: the registrations against the generating transform
+    terr = max(synth.pose_error(r["T64"], synth.t_true())[0] for r in results.values()) if results else 0.0
+    rerr = max(synth.pose_error(r["T64"], synth.t_true())[1] for r in results.values()) if results else 0.0
+    truth_bar = (0.05, 5e-3) if args.mode == "ref_cpp" else (5e-3, 5e-4)   # ref_cpp stops at its 5 cm mean-error rule
+    ok_truth = all(r["iterations"] == iters or args.mode != "p2plane" for r in results.values()) and terr < truth_bar[0] and rerr < truth_bar[1]
 
-    # ---------------- roofline of the dominant kernel (fused transform+NN+accumulate), HIP events
-    icp.use_graph(False)
-    icp.profile_enable(True)
-    prof_steps = max(2, min(5, args.steps))
-    for _ in range(prof_steps):
-        step()
-    torch.cuda.synchronize()
-    n_launch, ms_total = icp.profile_read()
-    icp.profile_enable(False)
-    a_nn = A_NN_P2PLANE if args.mode == "p2plane" else A_NN_P2P
-    nn_ms = ms_total / max(n_launch, 1)
-    queries_per_launch = n_scan * (B // parts) / (world if world > 1 else 1)   # the profiled part's launches
-    achieved_gbs = queries_per_launch * a_nn / (nn_ms * 1e-3) / 1e9 if nn_ms > 0 else 0.0
+    # ---------------- the dominant kernel (fused transform + NN + accumulate; ref_cpp: the search kernel), HIP events per launch
+    prof = None
+    if routed is None:
+        icp.use_graph(False)
+        icp.profile_enable(True)
+        prof_steps = max(2, min(4, args.steps))
+        for _ in range(prof_steps):
+            step()
+        torch.cuda.synchronize()
+        ms, sq, sw = icp.profile_launches()
+        icp.profile_enable(False)
+        icp.use_graph(not args.no_graph)
+        per = len(ms) // prof_steps
+        ms, sq, sw = (a[:per * prof_steps].reshape(prof_steps, per) for a in (ms, sq, sw))
+        q_launch = n_scan * B
+        waves = q_launch / 64.0
+        frac_search = sq.mean(0) / q_launch
+        searching = frac_search > 0.5 if args.mode != "ref_cpp" else ms.mean(0) > 5e-3
+        prof = dict(per=per, ms=ms.mean(0), frac_search=frac_search, wave_frac=sw.mean(0) / waves, searching=searching, q_launch=q_launch)
 
-    # ---------------- single-scan latency (one scan in flight, graph replay), outside the timed region
-    single_ms = None
-    if world == 1 and not sharded_run:
-        lat = api.Icp(ctx, max_dist, args.iters, 0.05, 1e-5)
-        lat.set_target(mp)
+    # ---------------- untimed extra legs: no-reuse throughput, upload-inclusive rate, single-scan latency
+    extras = {}
+    if routed is None and not args.no_extras:
+        k = max(3, min(10, args.steps))
+        if args.mode != "ref_cpp" and not args.no_nn_reuse:
+            icp.set_nn_reuse(False)
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k):
+                step()
+            torch.cuda.synchronize()
+            extras["value_no_reuse"] = B * k / (time.perf_counter() - t1)
+            icp.set_nn_reuse(True)
+        # upload-inclusive: every step uploads its batch from pinned host memory (two icp objects on two streams, so one
+        # batch's H2D copy runs under the other's kernels) -- what a sensor-fed pipeline sees
+        pinned = torch.from_numpy(scans).pin_memory()
+        pair = []
+        for _ in range(2):
+            st2 = torch.cuda.Stream()
+            c2 = api.Context(device, st2.cuda_stream)
+            i2 = new_icp(c2)
+            i2.set_source_batch_host_ptr(pinned.data_ptr(), n_scan, B)
+            i2.set_initial_batch(None)
+            i2.align_batch_async(args.mode)
+            pair.append((c2, i2))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for s_ in range(k):
+            c2, i2 = pair[s_ % 2]
+            i2.set_source_batch_host_ptr(pinned.data_ptr(), n_scan, B)
+            i2.align_batch_async(args.mode)
+        torch.cuda.synchronize()
+        extras["value_upload_inclusive"] = B * k / (time.perf_counter() - t1)
+        extras["upload_bytes_per_step"] = int(scans.nbytes)
+        for c2, i2 in pair:
+            i2.close()
+        del pinned
+        lat = new_icp()
         lat.set_source(scans[0])
-        lat.use_graph(not args.no_graph)
-        lat.set_query_order(args.query_order)
-        lat.set_nn_reuse(not args.no_nn_reuse)
         lat.align(args.mode)
         tl = time.perf_counter()
         for _ in range(10):
             lat.align(args.mode)
-        single_ms = (time.perf_counter() - tl) / 10 * 1e3
+        extras["single_scan_latency_ms"] = (time.perf_counter() - tl) / 10 * 1e3
+        lat.close()
 
-    # ---------------- HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this
-    # process, so the figure comes from the rocprofv3 --pmc passes of this same command committed under
-    # profiles/ (request counts x request sizes, i.e. with the gfx950 FETCH_SIZE x2 correction made
-    # explicit); reported only when the configuration matches the profiled one, otherwise null.
-    traffic, traffic_src = None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        c = tj["config"]
-        if (world == 1 and c["batch"] == B and c["scan_points"] == n_scan and c["map_points"] == args.map_points
-                and c["iters"] == args.iters and c["mode"] == args.mode):
-            traffic = tj["traffic_bytes_per_launch"]
-            traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ by request size, separate passes)"
-    except (OSError, KeyError, ValueError):
-        pass
+    # ---------------- roofline of the dominant kernel
+    # achieved = bytes the memory system moves per launch / launch duration: from the rocprofv3 PMC passes of this same
+    # command committed under profiles/ (request counts x request sizes, the gfx950 FETCH_SIZE x2 correction made explicit)
+    # when the configuration matches, else from the compulsory-traffic model below.  The SURVEY §8d convention
+    # (754 B per query-iteration whether or not a search runs) is reported beside it as an "effective" figure: the
+    # implementation proves most searches unnecessary, so that figure is a speed-up measure, not a roofline fraction.
+    a_nn = A_NN_P2PLANE if args.mode == "p2plane" else A_NN_P2P
+    roof = None
+    if prof is not None:
+        nn_ms = float(prof["ms"].mean())
+        cache_b = 48 if args.mode == "p2plane" else 32          # neighbour cache entry (3 / 2 float4 streams)
+        map_b = len(mp) * (32 if args.mode == "p2plane" else 16) + 4.0 * np.prod(mp.cell_size()[1])   # every point (+ normal) line and the cell table once
+        sel_s, sel_v = prof["searching"], ~prof["searching"]
+        if args.mode == "ref_cpp":
+            comp_search = prof["q_launch"] * (12 + 4) + map_b
+            comp_verify = 0.0
+        else:
+            comp_search = prof["q_launch"] * (12 + (cache_b if not args.no_nn_reuse else 0)) + map_b
+            comp_verify = prof["q_launch"] * (12 + cache_b)
+        comp = np.where(sel_s, comp_search, comp_verify)
+        traffic, traffic_src, valu = None, None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            c = tj["config"]
+            if (world == 1 and c["batch"] == B and c["scan_points"] == n_scan and c["map_points"] == args.map_points and c["iters"] == iters
+                    and c["mode"] == args.mode and c.get("nn_reuse", True) == (not args.no_nn_reuse)):
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = "profiles/r02_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ by request size, separate passes)"
+                valu = tj.get("valu")
+        except (OSError, KeyError, ValueError):
+            pass
+        bytes_launch = traffic if traffic is not None else float(comp.mean())
+        achieved = bytes_launch / (nn_ms * 1e-3) / 1e9 if nn_ms > 0 else 0.0
+
+        def phase(sel):
+            if not sel.any():
+                return None
+            return {"launches_per_alignment": int(sel.sum()), "avg_launch_us": float(prof["ms"][sel].mean() * 1e3),
+                    "queries_searching_frac": float(prof["frac_search"][sel].mean()), "waves_searching_frac": float(prof["wave_frac"][sel].mean()),
+                    "compulsory_bytes_per_launch": float(comp[sel].mean()),
+                    "compulsory_gbs": float(comp[sel].mean() / (prof["ms"][sel].mean() * 1e-3) / 1e9),
+                    "compulsory_frac_of_hbm_peak": float(comp[sel].mean() / (prof["ms"][sel].mean() * 1e-3) / 1e9 / HBM_PEAK_GBS)}
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                "achieved_from": "PMC traffic" if traffic is not None else "compulsory-traffic model (every touched map line once + query / neighbour-cache streams)",
+                "kernel": "k_ref_nn" if args.mode == "ref_cpp" else "k_nn_red", "avg_launch_ms": nn_ms, "launches_per_alignment": int(prof["per"]),
+                "queries_per_launch": prof["q_launch"],
+                "phases": {"searching": phase(sel_s), "verifying": phase(sel_v)},
+                "per_launch_us": [round(float(v) * 1e3, 1) for v in prof["ms"]],
+                "per_launch_queries_searching_frac": [round(float(v), 4) for v in prof["frac_search"]],
+                "effective_algorithmic": {"bytes_per_query": a_nn, "bytes_per_launch": prof["q_launch"] * a_nn,
+                                          "gbs": prof["q_launch"] * a_nn / (nn_ms * 1e-3) / 1e9,
+                                          "x_hbm_peak": prof["q_launch"] * a_nn / (nn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "note": "SURVEY §8d convention: 754 B charged per query-iteration whether or not a search runs; > 1 x peak means searches were proven unnecessary or served from L2, it is not a roofline fraction"}}
+        if valu is not None:
+            # what binds a searching launch: vector-instruction issue (profiles/: SQ_INSTS_VALU per wave, SQ_ACTIVE_INST_VALU utilisation)
+            roof["valu_issue"] = valu
 
     scans_total = B * args.steps
     value = scans_total / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    nn_per_scan = args.iters + (1 if args.mode == "o3d_p2p" else 0)
+    nn_per_scan = iters + (1 if args.mode == "o3d_p2p" else 0)
     out = {
         "metric": "scans_per_s_200k_scan_vs_10M_map",
         "value": value,
@@ -233,55 +419,68 @@ def main():
         "ms_per_step": ms_per_step,
         "ms_per_icp_iter": ms_per_step / nn_per_scan / B,
         "ms_per_icp_iter_batch": ms_per_step / nn_per_scan,
-        "single_scan_latency_ms": single_ms,
+        "single_scan_latency_ms": extras.get("single_scan_latency_ms"),
+        "value_no_reuse": extras.get("value_no_reuse"),
+        "value_upload_inclusive": extras.get("value_upload_inclusive"),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32 points / f64 accumulation",
+        "dtype": "f32 points / f64 accumulation" if args.mode != "ref_cpp" else "f32 points and updates (reference arithmetic) / f64 accumulation",
         "data": "synthetic",
-        "config": {"workload": "%dk-pt scans vs %.1fM-pt map (voxel 0.1 m -> %d pts), %d %s ICP iters, NN every iter"
-                               % (n_scan // 1000, args.map_points / 1e6, n_map, args.iters, args.mode),
-                   "scans_in_flight": B, "scans_in_flight_per_gpu": args.batch, "cell_m": args.cell, "max_corr_dist_m": max_dist,
-                   "parallelism": ("map sharded into %d x-slabs (+halo), every rank owns 1/%d of each scan's queries, RCCL all-reduce of the "
-                                   "normal-equation records once per ICP iteration" % (world, world)) if sharded_run else "single GPU",
+        "config": {"workload": "%dk-pt scans (%s) vs %.1fM-pt map (voxel 0.1 m -> %d pts), %d %s ICP iters, %s"
+                               % (n_scan // 1000, "drawn from the whole map" if args.scan_kind == "whole" else "10 m neighbourhoods", args.map_points / 1e6, n_map, iters,
+                                  args.mode, "lazy re-search (reference rule)" if args.mode == "ref_cpp" else
+                                  ("exact NN result every iter; neighbour reuse %s" % ("off: every query searches in every iteration" if args.no_nn_reuse else
+                                                                                     "on: a query whose neighbour provably cannot have changed skips its search (bit-identical results)"))),
+                   "mode": args.mode, "scans_in_flight": B, "scans_in_flight_per_gpu": B // world if args.scaling == "weak" else B, "cell_m": args.cell,
+                   "max_corr_dist_m": max_dist, "nn_reuse": not args.no_nn_reuse, "scan_kind": args.scan_kind,
+                   "parallelism": ("map sharded into %d x-slabs (+halo); %s; collective: %s"
+                                   % (world, "every scan spans every slab: each rank owns 1/%d of every scan's queries, all-reduce of the normal-equation records once per ICP iteration" % world
+                                      if args.scan_kind == "whole" else "scans routed to the slabs they touch, one-slab scans registered by one rank without a collective", comm_kind))
+                   if sharded_run else "single GPU",
                    "hip_graph": (not args.no_graph) and not sharded_run,
-                   "shard_resumes": (drv.resumes if drv is not None else 0), "pipeline_parts": parts},
-        "parity": {"max_translation_err_vs_truth_m": terr, "max_rotation_err_vs_truth_rad": rerr, "ok": bool(ok)},
-        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": queries_per_launch * a_nn,
-                     "kernel": "k_nn_red", "avg_launch_ms": nn_ms, "launches_timed": n_launch,
-                     "algorithmic_bytes_per_query": a_nn, "queries_per_launch": queries_per_launch},
+                   "shard_resumes": (routed.resumes if routed is not None else 0),
+                   "routing_groups": ({"%d-%d" % k: len(v) for k, v in routed.groups.items()} if routed is not None else None)},
+        "parity": {"max_translation_err_vs_truth_m": terr, "max_rotation_err_vs_truth_rad": rerr, "ok": bool(ok_truth)},
+        "roofline": roof,
         "setup_s": setup_s,
     }
 
-    # ---------------- CPU baseline: the oracle (port of the reference path), 1 thread, rank 0, N=1
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---------------- CPU baseline: the oracle (port of the reference path), 1 thread, rank 0, N=1 -- and the parity gate
+    if rank == 0 and world == 1 and not sharded_run and not args.no_cpu_baseline:
         from oracle import oracle as orc
-        normals, _ = mp.download_normals()
         tb = time.perf_counter()
         tree = orc.KdTreeD(map_ds.astype(np.float64))
         build_s = time.perf_counter() - tb
         del tree
-        it = args.cpu_baseline_iters
         tc = time.perf_counter()
         if args.mode == "p2plane":
-            r = orc.icp_p2plane(scans[0], map_ds, normals, max_dist=max_dist, num_iters=it)
+            normals, _ = mp.download_normals()
+            tc = time.perf_counter()
+            r = orc.icp_p2plane(scans[0], map_ds, normals, max_dist=max_dist, num_iters=iters)
+            what = "oracle/icp.c orc_icp_p2plane (kd-tree leaf 15, float64)"
+        elif args.mode == "o3d_p2p":
+            r = orc.icp_o3d_p2p(scans[0], map_ds, max_dist=max_dist, max_iter=iters)
+            what = "oracle/icp.c orc_icp_o3d_p2p (kd-tree leaf 15, float64; restates Open3D registration_icp)"
         else:
-            r = orc.icp_o3d_p2p(scans[0], map_ds, max_dist=max_dist, max_iter=it)
-        cpu_s = time.perf_counter() - tc - build_s
-        cpu_s = max(cpu_s, 1e-9)
-        cpu_scans_per_s = 1.0 / (cpu_s * args.iters / max(r["iterations"], 1))
+            r = orc.icp_ref_cpp(scans[0], map_ds, None, max_dist, iters, 0.05, 1e-5, precise=True)
+            what = "oracle/icp.c orc_icp_ref_cpp (restates icp_point_to_point.cpp:185-254; kd-tree leaf 15)"
+        cpu_s = max(time.perf_counter() - tc - build_s, 1e-9)
         dt, dr = synth.pose_error(results[0]["T64"], r["T"])
-        out["cpu_baseline"] = {"value": cpu_scans_per_s, "unit": "scans/s", "cores": 1, "kind": "port",
-                               "sample": "1 scan (%d pts) x %d ICP iterations of oracle/icp.c (kd-tree leaf 15, float64), "
-                                         "kd-tree build (%.1f s) excluded like the GPU index build; host has %d cores"
-                                         % (n_scan, r["iterations"], build_s, os.cpu_count()),
-                               "gpu_vs_oracle_translation_m": dt, "gpu_vs_oracle_rotation_rad": dr}
+        out["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "scans/s", "cores": 1, "kind": "port",
+                               "sample": "1 scan (%d pts), %d ICP iterations of %s, kd-tree build (%.1f s) excluded like the GPU index build; host has %d cores"
+                                         % (n_scan, r["iterations"], what, build_s, os.cpu_count()),
+                               "gpu_vs_oracle_translation_m": dt, "gpu_vs_oracle_rotation_rad": dr,
+                               "gpu_vs_oracle_iterations": [int(results[0]["iterations"]), int(r["iterations"])]}
+        out["parity"]["gpu_vs_oracle_ok"] = bool(dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and results[0]["iterations"] == r["iterations"])
+        out["parity"]["ok"] = bool(out["parity"]["ok"] and out["parity"]["gpu_vs_oracle_ok"])
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and not out["parity"]["ok"]:
+        print("bench.py: PARITY FAILED: %s" % json.dumps(out["parity"]), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -289,6 +289,9 @@ int sf_shard_route(const float *xyz, int64_t n_per_scan, int batch, const double
  * stream; sf_icp_profile_read returns launches and summed milliseconds since enabling. */
 int sf_icp_profile_enable(sf_icp *icp, int on);
 int sf_icp_profile_read(sf_icp *icp, int64_t *nn_launches, double *nn_ms_total);
+/* every profiled NN launch in launch order: duration [ms] and, for the fused O3D_P2P / P2PLANE kernel, how many queries and
+ * waves ran the search in it (the rest kept their certified neighbour); any output may be NULL, *n = launches recorded */
+int sf_icp_profile_read_launches(sf_icp *icp, float *ms, uint32_t *searched_queries, uint32_t *searched_waves, int64_t cap, int64_t *n);
 
 /* ------------------------------------------------------------------ BruteForceAlignment (start-up coarse lock) */
 /* localization/include/localization/brute_force_alignment.h:22-112 and

@@ -435,6 +435,12 @@ class Icp:
         _check(self.lib.sf_icp_set_source_batch(self.h, _p(xyz), C.c_int64(xyz.shape[1]), C.c_int(xyz.shape[0])))
         self.batch = xyz.shape[0]
 
+    def set_source_batch_host_ptr(self, ptr, n_per_scan, batch):
+        """batch x n_per_scan x 3 float32 at a raw HOST address (e.g. pinned memory: the copy is then asynchronous and
+        stream-ordered -- the buffer must stay untouched until the stream has passed it)"""
+        _check(self.lib.sf_icp_set_source_batch(self.h, C.c_void_p(ptr), C.c_int64(n_per_scan), C.c_int(batch)))
+        self.batch = batch
+
     def set_source_batch_device(self, ptr, n_per_scan, batch):
         _check(self.lib.sf_icp_set_source_batch_device(self.h, C.c_void_p(ptr), C.c_int64(n_per_scan), C.c_int(batch)))
         self.batch = batch
@@ -526,6 +532,16 @@ class Icp:
         n, ms = C.c_int64(), C.c_double()
         _check(self.lib.sf_icp_profile_read(self.h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def profile_launches(self):
+        """-> (ms[k], searched_queries[k], searched_waves[k]) of every profiled NN launch, in launch order"""
+        n = C.c_int64()
+        _check(self.lib.sf_icp_profile_read_launches(self.h, None, None, None, C.c_int64(0), C.byref(n)))
+        ms = np.empty(max(n.value, 1), np.float32)
+        q = np.empty(max(n.value, 1), np.uint32)
+        w = np.empty(max(n.value, 1), np.uint32)
+        _check(self.lib.sf_icp_profile_read_launches(self.h, _p(ms), _p(q), _p(w), C.c_int64(len(ms)), C.byref(n)))
+        return ms[:n.value], q[:n.value], w[:n.value]
 
     def close(self):
         if self.h:

@@ -409,12 +409,16 @@ __global__ void k_soa_from_aos(const float *__restrict__ aos, int64_t n, float *
     rec[i] = make_float4(a, b, c, 0.0f);
 }
 
-__global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict__ inits, int batch)
+// small batches carry their initial transforms in the kernel arguments (no copy, nothing for the host to wait on)
+constexpr int INIT_ARGS_MAX = 8;
+struct InitArgs { double T[INIT_ARGS_MAX][16]; };
+
+__global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict__ inits, InitArgs args, int batch)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     IcpState s;
-    for (int i = 0; i < 16; ++i) s.T[i] = inits[16 * b + i];
+    for (int i = 0; i < 16; ++i) s.T[i] = inits ? inits[16 * b + i] : args.T[b][i];
     for (int i = 0; i < REC_STRIDE; ++i) s.rec[i] = 0;
     s.fitness = s.rmse = s.prev_fitness = s.prev_rmse = 0;
     s.last_error = FLT_MAX; // icp_point_to_point.cpp:205
@@ -434,6 +438,7 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
 // added and go through ONE wave reduction.  Measured: QPL = 2 (half the reductions and slab rows,
 // 87 instead of 80 VGPR) is within 1 % of QPL = 1 at 1, 8 and 32 scans in flight -- the simpler one stays.
 constexpr int QPL = 1;
+constexpr int NN_STATS_SHARDS = 256; // counters of one profiled launch
 
 struct LanePair {
     double sx, sy, sz; // the transformed scan point (float64)
@@ -445,7 +450,7 @@ struct LanePair {
 template <int MODE, bool WINDOW, bool SHARD>
 __device__ __forceinline__ LanePair nn_pair(const SfGrid &g, const SfWindow &w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                             int n, int b, const IcpState *S, float thr, float xlo, float xhi, const uint32_t *__restrict__ own_off,
-                                            float4 *__restrict__ qcache, int64_t cache_n, int slot, int n_live, sf::WaveNN *ws)
+                                            float4 *__restrict__ qcache, int64_t cache_n, int slot, int n_live, sf::WaveNN *ws, uint32_t *__restrict__ stats)
 {
     double sx = 0, sy = 0, sz = 0;
     float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -505,7 +510,13 @@ __device__ __forceinline__ LanePair nn_pair(const SfGrid &g, const SfWindow &w, 
         }
     }
     // every lane takes part in the search (lanes without a query still execute other lanes' tasks)
-    if (__ballot(need) != 0ull) {
+    const unsigned long long need_mask = __ballot(need);
+    if (stats && (threadIdx.x & 63) == 0 && need_mask) { // profiling only (integer counters: order independent); sharded: one address would serialise 100 k waves
+        uint32_t *sh = stats + 2 * ((blockIdx.x + blockIdx.y * gridDim.x) & (NN_STATS_SHARDS - 1));
+        atomicAdd(&sh[0], (uint32_t)__popcll(need_mask));
+        atomicAdd(&sh[1], 1u);
+    }
+    if (need_mask != 0ull) {
         const sf::NNHit h = sf::nn_search_wave<WINDOW>(g, w, need, qx, qy, qz, thr, ws);
         if (need) {
             hit = h;
@@ -591,7 +602,7 @@ __device__ __forceinline__ void add_half(const PairTerms &t, int h, double (&v)[
 template <int MODE, bool WINDOW, bool SHARD>
 __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                                 int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks,
-                                                const uint32_t *__restrict__ own_off, float4 *__restrict__ qcache, int64_t cache_n)
+                                                const uint32_t *__restrict__ own_off, float4 *__restrict__ qcache, int64_t cache_n, uint32_t *__restrict__ stats)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in launch order, so
@@ -619,7 +630,7 @@ __global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const f
 #pragma unroll
     for (int u = 0; u < QPL; ++u) {
         const int slot = bx * (BLK * QPL) + u * BLK + (int)threadIdx.x;
-        const LanePair P = nn_pair<MODE, WINDOW, SHARD>(g, w, X0x, X0y, X0z, n, b, S, thr, xlo, xhi, own_off, qcache, cache_n, slot, n_live, &nn_ws[wv]);
+        const LanePair P = nn_pair<MODE, WINDOW, SHARD>(g, w, X0x, X0y, X0z, n, b, S, thr, xlo, xhi, own_off, qcache, cache_n, slot, n_live, &nn_ws[wv], stats);
         T[u] = pair_terms<MODE>(P);
     }
     // the lane's pairs added, reduced over the wave in two halves of 16 values (keeps the live
@@ -1007,19 +1018,27 @@ __global__ void k_ref_init(const float *__restrict__ X0x, const float *__restric
 
 // sourceTargetCorrespondences (icp_point_to_point.cpp:57-84): points without a match die
 // for good (corr = -1), the survivors remember the sorted position of their target.
+// The wave-cooperative search of sf_nn.hpp (every lane of a wave takes part, dead points and the tail included);
+// workgroups are placed like k_nn_red's: each XCD sweeps a contiguous eighth of the (cell-ordered) chunks for all scans
+// in flight.  grid.x is padded to a multiple of 8.
 template <bool WINDOW>
 __global__ __launch_bounds__(BLK) void k_ref_nn(SfGrid g, SfWindow w, const float *__restrict__ Xx, const float *__restrict__ Xy, const float *__restrict__ Xz, int n,
-                                                const IcpState *__restrict__ st, float thr, int force, int32_t *__restrict__ corr)
+                                                const IcpState *__restrict__ st, float thr, int force, int32_t *__restrict__ corr, int nblocks)
 {
-    const int b = blockIdx.y;
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int kk = L >> 3;
+    const int b = kk % (int)gridDim.y;
+    const int bx = (L & 7) * ((int)gridDim.x >> 3) + kk / (int)gridDim.y;
+    if (bx >= nblocks) return;
     const IcpState *S = st + b;
     if (S->done || !(force || S->research)) return;
-    const int i = blockIdx.x * BLK + threadIdx.x;
-    if (i >= n) return;
-    const size_t o = (size_t)b * n + i;
-    if (corr[o] < 0) return;
-    const sf::NNHit hit = sf::nn_search<WINDOW>(g, w, Xx[o], Xy[o], Xz[o], thr);
-    corr[o] = hit.j;
+    __shared__ sf::WaveNN nn_ws[BLK / 64];
+    const int i = bx * BLK + threadIdx.x;
+    const size_t o = (size_t)b * n + (size_t)(i < n ? i : 0);
+    const bool live = i < n && corr[o] >= 0;
+    const float qx = live ? Xx[o] : 0.0f, qy = live ? Xy[o] : 0.0f, qz = live ? Xz[o] : 0.0f;
+    const sf::NNHit hit = sf::nn_search_wave<WINDOW>(g, w, live, qx, qy, qz, thr, &nn_ws[threadIdx.x >> 6]);
+    if (live) corr[o] = hit.j;
 }
 
 // optional in-place X <- step * X (float32, unfused), then the 17-scalar record over the
@@ -1146,6 +1165,12 @@ struct sf_icp {
     int64_t n = 0;           // points per scan
     int batch = 0;
     std::vector<double> inits; // batch * 16
+    std::vector<double> inits_uploaded; // what d_inits holds (the copy is skipped while nothing changed)
+    double *h_inits = nullptr;          // pinned staging of the batch's initial transforms
+    size_t h_inits_cap = 0;
+    hipEvent_t inits_ev = nullptr;      // recorded after the staging buffer's last copy
+    bool inits_ev_pending = false;
+    uint32_t d_inits_epoch = 0xffffffffu;
     bool have_source = false;
     // target
     sf_map *map = nullptr;
@@ -1194,6 +1219,10 @@ struct sf_icp {
     size_t ev_used = 0;
     int64_t prof_launches = 0;
     double prof_ms = 0;
+    std::vector<float> prof_each;   // duration of every profiled launch, in launch order
+    sf::DevBuf nn_stats;            // per profiled k_nn_red launch: {queries that searched, waves that searched}
+    int64_t nn_stats_used = 0;
+    static constexpr int64_t NN_STATS_CAP = 1024;
 };
 
 namespace {
@@ -1270,7 +1299,7 @@ int order_queries(sf_icp *icp, int mode)
     const int64_t total = icp->n * icp->batch;
     const bool want = icp->order == SF_ORDER_CELL || (icp->order == SF_ORDER_AUTO && total >= ORDER_AUTO_MIN_QUERIES);
     icp->ordered = false;
-    if (!want || mode == SF_ICP_REF_CPP || total == 0 || icp->map->grid.n == 0) return SF_OK;
+    if (!want || total == 0 || icp->map->grid.n == 0) return SF_OK;
     SF_TRY(run_order_sort(icp, icp->batch, icp->n, total, nullptr, nullptr));
     icp->ordered = true;
     return SF_OK;
@@ -1341,7 +1370,7 @@ void prof_collect(sf_icp *icp)
 {
     for (size_t k = 0; k + 1 < icp->ev_used; k += 2) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, icp->ev[k], icp->ev[k + 1]) == hipSuccess) { icp->prof_ms += ms; icp->prof_launches += 1; }
+        if (hipEventElapsedTime(&ms, icp->ev[k], icp->ev[k + 1]) == hipSuccess) { icp->prof_ms += ms; icp->prof_launches += 1; icp->prof_each.push_back(ms); }
     }
     icp->ev_used = 0;
 }
@@ -1374,10 +1403,12 @@ void launch_nn_red(sf_icp *icp, bool sharded = false)
     const float thr = o3d_thr(icp);
     hipStream_t s = icp->ctx->stream;
     ProfScope ps(icp);
+    uint32_t *stats = nullptr;
+    if (icp->profiling && icp->nn_stats.p && icp->nn_stats_used < sf_icp::NN_STATS_CAP) stats = icp->nn_stats.as<uint32_t>() + 2 * NN_STATS_SHARDS * icp->nn_stats_used++;
     const bool win = m->window.kind != 0;
 #define SF_LAUNCH_NNRED(W, S)                                                                                                                                    \
     hipLaunchKernelGGL((k_nn_red<MODE, W, S>), grid, blk, 0, s, m->grid, m->window, x, y, z, (int)icp->n, st, thr, icp->xlo, icp->xhi, part, nb, \
-                       icp->own_off.as<uint32_t>(), icp->reuse ? icp->qcache.as<float4>() : nullptr, icp->cache_n)
+                       icp->own_off.as<uint32_t>(), icp->reuse ? icp->qcache.as<float4>() : nullptr, icp->cache_n, stats)
     if (win && sharded) SF_LAUNCH_NNRED(true, true);
     else if (win) SF_LAUNCH_NNRED(true, false);
     else if (sharded) SF_LAUNCH_NNRED(false, true);
@@ -1385,12 +1416,38 @@ void launch_nn_red(sf_icp *icp, bool sharded = false)
 #undef SF_LAUNCH_NNRED
 }
 
-void launch_state_init(sf_icp *icp)
+// A hipMemcpyAsync from pageable memory makes the host wait until the stream has reached it -- that would turn every
+// "async" alignment into a host synchronisation (measured: it kept a second stream's upload from overlapping).  Small
+// batches travel in the kernel arguments; larger ones through a pinned staging buffer, and only when they changed.
+int launch_state_init(sf_icp *icp)
 {
     hipStream_t s = icp->ctx->stream;
-    hipError_t e = hipMemcpyAsync(icp->d_inits.p, icp->inits.data(), sizeof(double) * 16 * (size_t)icp->batch, hipMemcpyHostToDevice, s);
-    (void)e;
-    hipLaunchKernelGGL(k_state_init, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), icp->d_inits.as<double>(), icp->batch);
+    const int B = icp->batch;
+    InitArgs args;
+    if (B <= INIT_ARGS_MAX) {
+        std::memcpy(args.T, icp->inits.data(), sizeof(double) * 16 * (size_t)B);
+        hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, s, icp->state.as<IcpState>(), (const double *)nullptr, args, B);
+        return SF_OK;
+    }
+    const size_t bytes = sizeof(double) * 16 * (size_t)B;
+    if (icp->inits_uploaded != icp->inits || icp->d_inits_epoch != icp->d_inits.epoch) {
+        if (icp->h_inits_cap < bytes) {
+            if (icp->inits_ev_pending) { SF_HIP(hipEventSynchronize(icp->inits_ev)); icp->inits_ev_pending = false; }
+            if (icp->h_inits) { hipError_t e = hipHostFree(icp->h_inits); (void)e; icp->h_inits = nullptr; }
+            SF_HIP(hipHostMalloc((void **)&icp->h_inits, bytes * 2, hipHostMallocDefault));
+            icp->h_inits_cap = bytes * 2;
+        }
+        if (!icp->inits_ev) SF_HIP(hipEventCreateWithFlags(&icp->inits_ev, hipEventDisableTiming));
+        if (icp->inits_ev_pending) SF_HIP(hipEventSynchronize(icp->inits_ev)); // the previous copy has left the staging buffer
+        std::memcpy(icp->h_inits, icp->inits.data(), bytes);
+        SF_HIP(hipMemcpyAsync(icp->d_inits.p, icp->h_inits, bytes, hipMemcpyHostToDevice, s));
+        SF_HIP(hipEventRecord(icp->inits_ev, s));
+        icp->inits_ev_pending = true;
+        icp->inits_uploaded = icp->inits;
+        icp->d_inits_epoch = icp->d_inits.epoch;
+    }
+    hipLaunchKernelGGL(k_state_init, dim3(nblk(B, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), icp->d_inits.as<double>(), args, B);
+    return SF_OK;
 }
 
 // enqueue the whole alignment (no host synchronisation)
@@ -1422,16 +1479,17 @@ int enqueue_align(sf_icp *icp, int mode)
         const dim3 gpts(nblk(n), (unsigned)B), gred((unsigned)icp->nblocks, (unsigned)B);
         const bool win = m->window.kind != 0;
         const float thr = icp->prm.max_corr; // squared-vs-unsquared quirk, icp_point_to_point.cpp:70
+        const dim3 gnn((unsigned)((icp->nblocks + 7) & ~7), (unsigned)B); // see the XCD mapping in k_ref_nn
         auto nn = [&](int force) {
             ProfScope ps(icp);
-            if (win) hipLaunchKernelGGL(k_ref_nn<true>, gpts, dim3(BLK), 0, s, m->grid, m->window, Xx, Xy, Xz, n, st, thr, force, corr);
-            else hipLaunchKernelGGL(k_ref_nn<false>, gpts, dim3(BLK), 0, s, m->grid, m->window, Xx, Xy, Xz, n, st, thr, force, corr);
+            if (win) hipLaunchKernelGGL(k_ref_nn<true>, gnn, dim3(BLK), 0, s, m->grid, m->window, Xx, Xy, Xz, n, st, thr, force, corr, icp->nblocks);
+            else hipLaunchKernelGGL(k_ref_nn<false>, gnn, dim3(BLK), 0, s, m->grid, m->window, Xx, Xy, Xz, n, st, thr, force, corr, icp->nblocks);
         };
         auto red = [&](int apply, int only_research) {
             hipLaunchKernelGGL(k_ref_red, gred, dim3(BLK), 0, s, m->grid.pts, Xx, Xy, Xz, n, st, corr, apply, only_research, part, icp->nblocks);
         };
         auto decide = [&](int phase) { hipLaunchKernelGGL(k_ref_decide, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks, icp->prm, phase); };
-        hipLaunchKernelGGL(k_ref_init, gpts, dim3(BLK), 0, s, soa(icp->X0, total, 0), soa(icp->X0, total, 1), soa(icp->X0, total, 2), n, st, Xx, Xy, Xz, corr);
+        hipLaunchKernelGGL(k_ref_init, gpts, dim3(BLK), 0, s, src(icp, 0), src(icp, 1), src(icp, 2), n, st, Xx, Xy, Xz, corr); // the cell-ordered copy when ordering is on
         nn(1);
         red(0, 0);
         decide(0);
@@ -1505,8 +1563,10 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     (void)e;
     if (icp->graph_exec) { e = hipGraphExecDestroy(icp->graph_exec); (void)e; }
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
+    if (icp->inits_ev) { e = hipEventDestroy(icp->inits_ev); (void)e; }
+    if (icp->h_inits) { e = hipHostFree(icp->h_inits); (void)e; }
     icp->X0.release(); icp->X0r.release(); icp->qcache.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
-    icp->d_box.release(); icp->stage.release(); icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
+    icp->nn_stats.release(); icp->d_box.release(); icp->stage.release(); icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
     sf_ctx *ctx = icp->ctx;
@@ -1630,7 +1690,7 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     SF_HIP(hipSetDevice(icp->ctx->device));
     hipStream_t s = icp->ctx->stream;
     icp->last_mode = mode;
-    launch_state_init(icp);
+    SF_TRY(launch_state_init(icp));
     SF_TRY(order_queries(icp, mode)); // plain launches ahead of the (replayed) iteration graph
     if (mode != SF_ICP_REF_CPP) SF_TRY(reuse_reset(icp, icp->n * icp->batch));
     if (icp->use_graph && !icp->profiling && icp->map->window.kind == 0) { // a window travels by value and moves with the pose: plain launches
@@ -1787,7 +1847,7 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
     SF_CHECK(first != 2 || icp->shard, SF_ERR_STATE, "resume (first = 2) is a sharded-path operation");
     SF_HIP(hipSetDevice(icp->ctx->device));
     icp->last_mode = mode;
-    if (first == 1) launch_state_init(icp);
+    if (first == 1) SF_TRY(launch_state_init(icp));
     if (icp->shard) {
         if (first) SF_TRY(shard_build(icp, first == 2));
     } else if (first) {
@@ -1821,6 +1881,31 @@ extern "C" int sf_icp_step_end(sf_icp *icp, int mode, int last)
     else
         hipLaunchKernelGGL(k_solve_only<2>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->d_box.as<ScanBox>(), icp->shard ? icp->own_margin : 0.0f);
     SF_HIP(hipGetLastError());
+    return SF_OK;
+}
+
+// every profiled NN launch since sf_icp_profile_enable, in launch order: its duration and -- for the fused
+// O3D_P2P / P2PLANE kernel -- how many queries / waves ran the search (the others kept their certified neighbour)
+extern "C" int sf_icp_profile_read_launches(sf_icp *icp, float *ms, uint32_t *searched_queries, uint32_t *searched_waves, int64_t cap, int64_t *n)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    SF_HIP(hipStreamSynchronize(icp->ctx->stream));
+    prof_collect(icp);
+    const int64_t have = (int64_t)icp->prof_each.size();
+    if (n) *n = have;
+    if (!ms && !searched_queries && !searched_waves) return SF_OK;
+    SF_CHECK(cap >= have, SF_ERR_INVALID, "buffer too small: %lld < %lld", (long long)cap, (long long)have);
+    const size_t per = (size_t)2 * NN_STATS_SHARDS;
+    std::vector<uint32_t> st(per * (size_t)std::max<int64_t>(icp->nn_stats_used, 1), 0u);
+    if (icp->nn_stats_used > 0) SF_HIP(hipMemcpy(st.data(), icp->nn_stats.p, sizeof(uint32_t) * per * (size_t)icp->nn_stats_used, hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < have; ++k) {
+        if (ms) ms[k] = icp->prof_each[(size_t)k];
+        uint64_t q = 0, w = 0;
+        if (k < icp->nn_stats_used && icp->last_mode != SF_ICP_REF_CPP)
+            for (int sh = 0; sh < NN_STATS_SHARDS; ++sh) { q += st[per * (size_t)k + 2 * sh]; w += st[per * (size_t)k + 2 * sh + 1]; }
+        if (searched_queries) searched_queries[k] = (uint32_t)q;
+        if (searched_waves) searched_waves[k] = (uint32_t)w;
+    }
     return SF_OK;
 }
 
@@ -1969,6 +2054,12 @@ extern "C" int sf_icp_profile_enable(sf_icp *icp, int on)
     icp->ev_used = 0;
     icp->prof_launches = 0;
     icp->prof_ms = 0;
+    icp->prof_each.clear();
+    icp->nn_stats_used = 0;
+    if (on) {
+        SF_TRY(icp->nn_stats.reserve(sizeof(uint32_t) * 2 * NN_STATS_SHARDS * sf_icp::NN_STATS_CAP));
+        SF_HIP(hipMemsetAsync(icp->nn_stats.p, 0, sizeof(uint32_t) * 2 * NN_STATS_SHARDS * sf_icp::NN_STATS_CAP, icp->ctx->stream));
+    }
     return SF_OK;
 }
 
