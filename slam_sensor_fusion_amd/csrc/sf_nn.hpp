@@ -66,14 +66,46 @@ __device__ __forceinline__ bool window_accepts(const SfWindow &w, float px, floa
     return true;
 }
 
-// TRACK: hit.lb2 follows the smallest squared distance among the examined candidates that did
-// not end up as the best (a displaced best included)
+// The best candidate is the LEXICOGRAPHIC minimum of (d2, j) over everything visited -- the same rule in every
+// search form, whatever the order ranges are walked in (a candidate at the acceptance threshold itself is never taken:
+// the tie rule needs a real best).
+// A lower bound of the distance from the query to every point the window accepts (0 when the query is inside the
+// window or the bound would be in doubt).  A point p passes a sphere window iff |p - c|^2 < r2, so every accepted point
+// is at least |q - c| - r away (triangle inequality); for a box window the largest single-axis excess does the same.
+// When that bound exceeds sqrt(thr) no candidate can be accepted AND close enough: the search of such a query is
+// skipped -- no result changes, only the ring walk that would end empty is spared (on the per-scan path the scan points
+// beyond the 10 m map crop of localization_node.cpp:302 are a large share of every scan) -- and the bound itself is the
+// query's runner-up bound for the neighbour-reuse certificate.
+__device__ __forceinline__ float window_gap(const SfWindow &w, float qx, float qy, float qz)
+{
+    if (w.kind == 1) {
+        const float dx = qx - w.c[0], dy = qy - w.c[1], dz = qz - w.c[2];
+        return fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) * 0.9995f - sqrtf(w.r2) * 1.0005f - 1.0e-4f, 0.0f);
+    }
+    if (w.kind == 2) {
+        const double d0 = (double)qx - w.oc[0], d1 = (double)qy - w.oc[1], d2 = (double)qz - w.oc[2];
+        double out = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { // the axes need not be orthonormal (the prior is a blend): an excess along axis k is a distance only after division by its norm
+            const double proj = d0 * w.oR[k] + d1 * w.oR[3 + k] + d2 * w.oR[6 + k];
+            const double n2 = w.oR[k] * w.oR[k] + w.oR[3 + k] * w.oR[3 + k] + w.oR[6 + k] * w.oR[6 + k];
+            const double over = fmax(fabs(proj) - w.ohalf[k], 0.0);
+            out = fmax(out, over / sqrt(fmax(n2, 1.0e-30)));
+        }
+        return fmaxf((float)out * 0.9995f - 1.0e-4f, 0.0f);
+    }
+    return 0.0f;
+}
+
+// TRACK: hit.lb2 follows the smallest squared distance among the examined candidates that did not end up as the
+// best (a displaced best included); the best itself, met again, is not "another point".
 template <bool WINDOW, bool TRACK = false>
 __device__ __forceinline__ void consider(const SfWindow &w, float px, float py, float pz, int j, bool valid, float qx, float qy, float qz, NNHit &hit)
 {
     const float d2 = l2_simple(qx, qy, qz, px, py, pz);
-    const bool take = valid && d2 < hit.d2 && (!WINDOW || window_accepts(w, px, py, pz));
-    if (TRACK && valid) hit.lb2 = fminf(hit.lb2, take ? hit.d2 : d2);
+    const bool better = d2 < hit.d2 || (d2 == hit.d2 && hit.j >= 0 && j < hit.j);
+    const bool take = valid && better && (!WINDOW || window_accepts(w, px, py, pz));
+    if (TRACK && valid && j != hit.j) hit.lb2 = fminf(hit.lb2, take ? hit.d2 : d2);
     if (take) {
         hit.d2 = d2;
         hit.j = j;
@@ -118,7 +150,8 @@ __device__ __forceinline__ void scan4(const SfGrid &g, const SfWindow &w, uint32
 #endif
 }
 
-// CSR candidates [a, b)
+// CSR candidates [a, b).  (Eight loads in flight per trip instead of four: measured slower at 32 scans in flight --
+// 545 -> 609 us for a searching launch, 89 -> 94 us for a verifying one -- and no faster on the per-scan path.)
 template <bool WINDOW, bool TRACK = false>
 __device__ __forceinline__ void scan_range(const SfGrid &g, const SfWindow &w, uint32_t a, uint32_t b, float qx, float qy, float qz, NNHit &hit)
 {
@@ -277,6 +310,10 @@ __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, f
     hit.px = hit.py = hit.pz = 0.0f;
     hit.lb2 = 0.0f;
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz)) || g.n == 0) return hit;
+    if (WINDOW) {
+        const float gap = window_gap(w, qx, qy, qz);
+        if (gap * gap > thr) return hit;
+    }
     nn_rings<WINDOW>(g, w, qx, qy, qz, 1, hit);
     return hit;
 }
@@ -350,8 +387,12 @@ __device__ __forceinline__ float row_gap2(const QueryGeo &G, int k)
 // the query to every OTHER map point (the runner-up among the examined candidates, the gaps of
 // everything that was pruned, the boundary of the 27-cell block) -- what k_nn_red needs to prove,
 // one iteration later, that the neighbour cannot have changed.
+// seed (optional, seed.j >= 0): a map point already known for this query -- its neighbour of an earlier search -- with its
+// CURRENT squared distance seed.d2 (l2_simple of the query and the point).  The search then starts from that bound
+// instead of the acceptance threshold: the same exact result (the seed is a candidate like any other, met again when
+// its range is scanned), most neighbour ranges pruned before they are visited.
 template <bool WINDOW>
-__device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow &w, bool valid, float qx, float qy, float qz, float thr, WaveNN *ws)
+__device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow &w, bool valid, float qx, float qy, float qz, float thr, WaveNN *ws, NNHit seed = NNHit{0.0f, -1, 0.0f, 0.0f, 0.0f, 0.0f})
 {
     const int lane = (int)__lane_id();
     const int nx = g.dim[0], ny = g.dim[1], nz = g.dim[2];
@@ -361,6 +402,14 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
     hit.px = hit.py = hit.pz = 0.0f;
     hit.lb2 = 3.0e38f;
     valid = valid && isfinite(qx) && isfinite(qy) && isfinite(qz) && g.n > 0;
+    if (WINDOW && valid) {
+        const float gap = window_gap(w, qx, qy, qz);
+        if (gap * gap > thr) { // nothing the window accepts is within the acceptance radius
+            hit.lb2 = gap * gap;
+            valid = false;
+        }
+    }
+    if (valid && seed.j >= 0 && seed.d2 < thr) { hit.d2 = seed.d2; hit.j = seed.j; hit.px = seed.px; hit.py = seed.py; hit.pz = seed.pz; }
     uint32_t mask = 0;
     if (valid) {
         const QueryGeo G = query_geo(g, qx, qy, qz);
@@ -411,7 +460,8 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
             const int owner = (int)(e >> 4), t = (int)(e & 15u);
             const float4 Q = ws->q[owner];
             const QueryGeo G = query_geo(g, Q.x, Q.y, Q.z);
-            const float cur = __uint_as_float((uint32_t)(__atomic_load_n(&ws->best[owner], __ATOMIC_RELAXED) >> 32));
+            const unsigned long long start = __atomic_load_n(&ws->best[owner], __ATOMIC_RELAXED);
+            const float cur = __uint_as_float((uint32_t)(start >> 32));
             const bool own_row = t < 2 || t == 10;
             const float g2 = own_row ? (t == 0 ? G.gxm2 : (t == 1 ? G.gxp2 : 0.0f)) : row_gap2(G, t - 2);
             float bound = g2; // what this task contributes to the owner's runner-up bound
@@ -430,17 +480,17 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
                     if (!xm && rb.s0 < rb.s1) bound = g2 + G.gxm2;
                     if (!xp && rb.s2 < rb.s3) bound = fminf(bound, g2 + G.gxp2);
                 }
+                // the task starts from the owner's best as it stands: ties are settled by the index rule of consider(),
+                // the best itself -- met again in its own range -- is neither taken nor counted as a runner-up
                 NNHit h;
-                // ties with the best this task started from are reported too (the packed minimum
-                // settles them by index), but never a candidate at the acceptance threshold itself
-                h.d2 = cur < thr ? __uint_as_float(__float_as_uint(cur) + 1u) : thr;
-                h.j = -1;
+                h.d2 = cur;
+                h.j = (int)(uint32_t)start;
                 h.px = h.py = h.pz = 0.0f;
                 h.lb2 = 3.0e38f;
                 scan_range<WINDOW, true>(g, w, a, b, Q.x, Q.y, Q.z, h);
                 bound = fminf(bound, h.lb2);
-                if (h.j >= 0) { // whichever of (previous best, this candidate) loses is a runner-up
-                    const unsigned long long mine = pack_hit(h.d2, h.j);
+                const unsigned long long mine = pack_hit(h.d2, h.j);
+                if (mine != start) { // something lexicographically smaller: whichever of (the best by now, this candidate) loses is a runner-up
                     const unsigned long long old = atomicMin(&ws->best[owner], mine);
                     bound = fminf(bound, __uint_as_float((uint32_t)((old > mine ? old : mine) >> 32)));
                 }

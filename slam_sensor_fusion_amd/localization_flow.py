@@ -19,6 +19,11 @@ class LocalizationFlow:
     ref_frame_distance_ = 3.0
     cloud_crop_radius_ = 10.0
     icp_mode_ = "ref_cpp"              # ICPPointToPoint::calculateAlignment (icp_point_to_point.cpp:185-254)
+    # grid cell of the whole-map index: the reference's "d2 < 0.5" rule (icp_point_to_point.cpp:70) is a 0.707 m search
+    # radius on a stride-3 map (0.3 m point spacing); a cell of that size keeps every search inside the 27-cell block
+    # (automatic sizing, 1.5 points per cell, sends each query without a neighbour through a second ring, lane by lane)
+    index_cell_ = 0.72
+    pcl_crop_order_ = False            # True: the scan crop keeps PCL's ascending-distance output order (point_cloud_processing.hpp:40-52)
 
     def __init__(self, ctx, map_points, map_T_global, altitude_table=None, map_is_downsampled=True):
         self.ctx = ctx
@@ -27,7 +32,7 @@ class LocalizationFlow:
             cloud.voxel_downsample(0.1, "pcl")              # getMapCloud(0.1f), :19
         cloud.subsample(3)                                   # applyUniformSubsample(map_cloud_, 3), :20
         self.map_cloud_ = cloud
-        self.map_index_ = api.Map(ctx, cloud, 0.0)
+        self.map_index_ = api.Map(ctx, cloud, self.index_cell_)
         self.map_T_global_ = np.asarray(map_T_global, dtype=np.float64)
         self.altitude_table_ = np.zeros((0, 3)) if altitude_table is None else np.asarray(altitude_table, dtype=np.float64)
         self.icp_ = api.Icp(ctx, 0.5, 10, 0.05, 1e-5)        # :24-28
@@ -125,7 +130,9 @@ class LocalizationFlow:
         else:
             scan.upload(scan_xyz)
         scan.subsample(2)
-        scan.crop_radius([0.0, 0.0, 0.0], self.cloud_crop_radius_, sorted=True)
+        # index order, not PCL's distance order: the order of the source points only moves the rounding of the float64
+        # record sums (the reference's own float32 sums depend on it far more), and the sort is 50 us + two allocations per scan
+        scan.crop_radius([0.0, 0.0, 0.0], self.cloud_crop_radius_, sorted=self.pcl_crop_order_)
         sensor_T_ref = api.mat4f_mul(api.mat4f_inverse(self.map_T_sensor_), self.map_T_ref_)
         if np.linalg.norm(sensor_T_ref[:3, 3].astype(np.float32)) > self.ref_frame_distance_ or not self.have_window_:
             self.map_index_.window_sphere(self.map_T_sensor_[:3, 3], self.cloud_crop_radius_)
