@@ -66,6 +66,10 @@ int sf_cloud_create(sf_ctx *ctx, sf_cloud **out);
 void sf_cloud_destroy(sf_cloud *c);
 int sf_cloud_upload(sf_cloud *c, const float *xyz, int64_t n);
 int sf_cloud_upload_f64(sf_cloud *c, const double *xyz, int64_t n); /* rounds to f32 */
+/* enqueue only (no host synchronisation): with PINNED host memory the copy is asynchronous and stream-ordered -- e.g. on a
+ * copy stream's context into a staging cloud that a compute stream picks up with sf_icp_set_source_batch_device */
+int sf_cloud_upload_async(sf_cloud *c, const float *xyz, int64_t n);
+void *sf_cloud_device_ptr(sf_cloud *c); /* float[n][3] on the device (valid until the cloud is modified) */
 int sf_cloud_from_device(sf_cloud *c, const void *d_xyz, int64_t n); /* device-to-device copy */
 int sf_cloud_size(sf_cloud *c, int64_t *n);
 int sf_cloud_download(sf_cloud *c, float *xyz, int64_t cap, int64_t *n);

@@ -78,6 +78,7 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     lib.sf_last_error.restype = C.c_char_p
     lib.sf_ctx_stream.restype = C.c_void_p
+    lib.sf_cloud_device_ptr.restype = C.c_void_p
     lib.sf_icp_exchange_ptr.restype = C.c_void_p
     lib.sf_sfilter_create.restype = C.c_void_p
     lib.sf_fusion_compass_to_yaw.restype = C.c_float
@@ -152,6 +153,14 @@ class Cloud:
         xyz = _f32(xyz).reshape(-1, 3)
         _check(self.lib.sf_cloud_upload(self.h, _p(xyz), C.c_int64(len(xyz))))
         return self
+
+    def upload_async_ptr(self, host_ptr, n):
+        """n x 3 float32 at a raw host address, enqueue only (pinned memory: asynchronous, stream-ordered)"""
+        _check(self.lib.sf_cloud_upload_async(self.h, C.c_void_p(host_ptr), C.c_int64(n)))
+        return self
+
+    def device_ptr(self):
+        return self.lib.sf_cloud_device_ptr(self.h)
 
     def from_pointcloud2(self, msg):
         """PointCloud2-like message (width, height, point_step, row_step, is_bigendian, fields or x/y/z float32 at

@@ -152,6 +152,21 @@ extern "C" int sf_cloud_upload(sf_cloud *c, const float *xyz, int64_t n)
     return SF_OK;
 }
 
+// enqueue only: for PINNED host memory the copy is asynchronous and stream-ordered (the caller keeps the buffer
+// untouched until the stream has passed it); pageable memory is staged by the runtime before the call returns
+extern "C" int sf_cloud_upload_async(sf_cloud *c, const float *xyz, int64_t n)
+{
+    SF_CHECK(c && n >= 0 && (xyz || n == 0), SF_ERR_INVALID, "bad arguments");
+    SF_HIP(hipSetDevice(c->ctx->device));
+    SF_TRY(c->xyz.reserve(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1)));
+    if (n > 0) SF_HIP(hipMemcpyAsync(c->xyz.p, xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, c->ctx->stream));
+    c->n = n;
+    cloud_reset_meta(c);
+    return SF_OK;
+}
+
+extern "C" void *sf_cloud_device_ptr(sf_cloud *c) { return c ? c->xyz.p : nullptr; }
+
 extern "C" int sf_cloud_upload_f64(sf_cloud *c, const double *xyz, int64_t n)
 {
     SF_CHECK(c && n >= 0 && (xyz || n == 0), SF_ERR_INVALID, "bad arguments");
