@@ -40,34 +40,6 @@ namespace {
 constexpr int BLK = 256;
 inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)sf::div_up(n > 0 ? n : 1, b); }
 
-__device__ __forceinline__ double bf_swap_add_32(double a, double b)
-{
-    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-}
-
-template <int CTRL>
-__device__ __forceinline__ double bf_dpp(double v)
-{
-    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)__double2loint(v), CTRL, 0xf, 0xf, false);
-    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)__double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double((int)hi, (int)lo);
-}
-
-// 64-lane total in every lane, fixed order (permlane32 swap, row_ror 16/8, half mirror, quad perms)
-__device__ __forceinline__ double bf_wave_sum(double v)
-{
-    v = bf_swap_add_32(v, v);
-    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
-    v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-    v = v + bf_dpp<0x128>(v);
-    v = v + bf_dpp<0x141>(v);
-    v = v + bf_dpp<0x4e>(v);
-    return v + bf_dpp<0xb1>(v);
-}
-
 __global__ void k_bf_soa(const float *__restrict__ aos, int64_t n, float *__restrict__ x, float *__restrict__ y, float *__restrict__ z)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,39 +47,49 @@ __global__ void k_bf_soa(const float *__restrict__ aos, int64_t n, float *__rest
     x[i] = aos[3 * i]; y[i] = aos[3 * i + 1]; z[i] = aos[3 * i + 2];
 }
 
-// score partials: grid (point blocks, candidates); T * Vector4f(p, 1) in float32, unfused,
-// column combination with k ascending (brute_force_alignment.cpp:98); NN d2 unbounded (:102)
+// every (candidate, source point) squared NN distance: grid (point blocks, candidates); T * Vector4f(p, 1) in float32,
+// unfused, column combination with k ascending (brute_force_alignment.cpp:98); NN d2 unbounded (:102).  The search is
+// the wave-cooperative one of the ICP kernels (every lane of a wave takes part, the tail included).
 template <bool WINDOW>
 __global__ __launch_bounds__(BLK, 4) void k_bf_score(SfGrid g, SfWindow w, const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int n,
-                                                     const float *__restrict__ poses, double *__restrict__ partials, int nblocks)
+                                                     const float *__restrict__ poses, float *__restrict__ d2_out)
 {
+    __shared__ sf::WaveNN nn_ws[BLK / 64];
     const int c = blockIdx.y;
     const float *T = poses + (size_t)c * 12;
     const int i = blockIdx.x * BLK + threadIdx.x;
-    double d2 = 0.0;
-    if (i < n) {
+    const bool live = i < n;
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (live) {
         const float x = X[i], y = Y[i], z = Z[i];
-        const float qx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], x), __fmul_rn(T[1], y)), __fmul_rn(T[2], z)), T[3]);
-        const float qy = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], x), __fmul_rn(T[5], y)), __fmul_rn(T[6], z)), T[7]);
-        const float qz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], x), __fmul_rn(T[9], y)), __fmul_rn(T[10], z)), T[11]);
-        const sf::NNHit hit = sf::nn_search<WINDOW>(g, w, qx, qy, qz, 3.0e38f);
-        if (hit.j >= 0) d2 = (double)hit.d2;
+        qx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], x), __fmul_rn(T[1], y)), __fmul_rn(T[2], z)), T[3]);
+        qy = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], x), __fmul_rn(T[5], y)), __fmul_rn(T[6], z)), T[7]);
+        qz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], x), __fmul_rn(T[9], y)), __fmul_rn(T[10], z)), T[11]);
     }
-    const double total = bf_wave_sum(d2);
-    __shared__ double s[BLK / 64];
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = total;
-    __syncthreads();
-    if (threadIdx.x == 0) partials[(size_t)c * nblocks + blockIdx.x] = ((s[0] + s[1]) + s[2]) + s[3];
+    const sf::NNHit hit = sf::nn_search_wave<WINDOW>(g, w, live, qx, qy, qz, 3.0e38f, &nn_ws[threadIdx.x >> 6]);
+    if (live) d2_out[(size_t)c * n + i] = hit.j >= 0 ? hit.d2 : 0.0f;
 }
 
-// one wave per candidate: fixed-order sum of its block partials, / N, rounded to float
-__global__ __launch_bounds__(64) void k_bf_finish(const double *__restrict__ partials, int nblocks, int n, float *__restrict__ scores)
+// The reference adds the distances of one candidate SERIALLY in float32, in source order, and divides by N in float32
+// (brute_force_alignment.cpp:95-105): a score within float32 summation error of the 0.1 threshold decides the early exit,
+// so the sum is reproduced bit for bit -- one wave per candidate loads 64 distances at a time (coalesced) and lane 0's
+// accumulator takes them in order through v_readlane.
+__global__ __launch_bounds__(64) void k_bf_finish(const float *__restrict__ d2, int n, float *__restrict__ scores)
 {
-    const int c = blockIdx.x;
-    double v = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) v += partials[(size_t)c * nblocks + b];
-    v = bf_wave_sum(v);
-    if (threadIdx.x == 0) scores[c] = (float)(v / (double)n);
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const float *row = d2 + (size_t)c * n;
+    float acc = 0.0f;
+    for (int base = 0; base < n; base += 64) {
+        const float v = base + lane < n ? row[base + lane] : 0.0f;
+        const int cnt = min(64, n - base);
+        if (cnt == 64) {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) acc = __fadd_rn(acc, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)));
+        } else {
+            for (int l = 0; l < cnt; ++l) acc = __fadd_rn(acc, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)));
+        }
+    }
+    if (lane == 0) scores[c] = __fdiv_rn(acc, (float)n);
 }
 
 // brute_force_alignment.cpp:148-180
@@ -241,7 +223,8 @@ extern "C" int sf_bf_align_clouds(sf_bf *bf, int *found)
     const int n = (int)bf->n;
     const int nblocks = (int)sf::div_up(n, BLK);
     SF_TRY(bf->poses.reserve(sizeof(float) * 12 * per_x));
-    SF_TRY(bf->partials.reserve(sizeof(double) * per_x * (size_t)nblocks));
+    SF_CHECK((double)per_x * (double)n < 2.0e9, SF_ERR_OVERFLOW, "%zu candidates x %d points per slice is too large", per_x, n);
+    SF_TRY(bf->partials.reserve(sizeof(float) * per_x * (size_t)n)); // one squared distance per (candidate of the slice, point)
     SF_TRY(bf->scores.reserve(sizeof(float) * per_x));
     std::vector<float> T(16 * total), hpose(12 * per_x), hscore(per_x);
     bf->last_scores.assign(total, NAN);
@@ -267,10 +250,10 @@ extern "C" int sf_bf_align_clouds(sf_bf *bf, int *found)
         SF_HIP(hipMemcpyAsync(bf->poses.p, hpose.data(), sizeof(float) * 12 * per_x, hipMemcpyHostToDevice, st));
         const dim3 grid((unsigned)nblocks, (unsigned)per_x);
         if (bf->target->window.kind)
-            hipLaunchKernelGGL(k_bf_score<true>, grid, dim3(BLK), 0, st, bf->target->grid, bf->target->window, X, Y, Z, n, bf->poses.as<float>(), bf->partials.as<double>(), nblocks);
+            hipLaunchKernelGGL(k_bf_score<true>, grid, dim3(BLK), 0, st, bf->target->grid, bf->target->window, X, Y, Z, n, bf->poses.as<float>(), bf->partials.as<float>());
         else
-            hipLaunchKernelGGL(k_bf_score<false>, grid, dim3(BLK), 0, st, bf->target->grid, bf->target->window, X, Y, Z, n, bf->poses.as<float>(), bf->partials.as<double>(), nblocks);
-        hipLaunchKernelGGL(k_bf_finish, dim3((unsigned)per_x), dim3(64), 0, st, bf->partials.as<double>(), nblocks, n, bf->scores.as<float>());
+            hipLaunchKernelGGL(k_bf_score<false>, grid, dim3(BLK), 0, st, bf->target->grid, bf->target->window, X, Y, Z, n, bf->poses.as<float>(), bf->partials.as<float>());
+        hipLaunchKernelGGL(k_bf_finish, dim3((unsigned)per_x), dim3(64), 0, st, bf->partials.as<float>(), n, bf->scores.as<float>());
         SF_HIP(hipGetLastError());
         SF_HIP(hipMemcpyAsync(hscore.data(), bf->scores.p, sizeof(float) * per_x, hipMemcpyDeviceToHost, st));
         SF_HIP(hipStreamSynchronize(st));

@@ -35,7 +35,7 @@
 namespace sf {
 
 struct NNHit {
-    float d2;         // squared distance of the best candidate (== threshold if none)
+    float d2;         // squared distance of the best candidate (the largest float below the threshold if none)
     int j;            // sorted position of the best candidate, -1 if none
     float px, py, pz; // its coordinates (kept in registers: re-reading the winner costs a round trip)
     float lb2;        // nn_search_wave only: every OTHER map point is at least sqrt(lb2) away from the query
@@ -66,9 +66,6 @@ __device__ __forceinline__ bool window_accepts(const SfWindow &w, float px, floa
     return true;
 }
 
-// The best candidate is the LEXICOGRAPHIC minimum of (d2, j) over everything visited -- the same rule in every
-// search form, whatever the order ranges are walked in (a candidate at the acceptance threshold itself is never taken:
-// the tie rule needs a real best).
 // A lower bound of the distance from the query to every point the window accepts (0 when the query is inside the
 // window or the bound would be in doubt).  A point p passes a sphere window iff |p - c|^2 < r2, so every accepted point
 // is at least |q - c| - r away (triangle inequality); for a box window the largest single-axis excess does the same.
@@ -97,14 +94,22 @@ __device__ __forceinline__ float window_gap(const SfWindow &w, float qx, float q
     return 0.0f;
 }
 
+// The best candidate is the LEXICOGRAPHIC minimum of (d2, j) over everything visited -- the same rule in every
+// search form, whatever the order ranges are walked in.  One 64-bit unsigned compare of (float bits of d2, index): d2
+// is a non-negative finite float, so its bit pattern orders like its value.  "No candidate yet" is the pair
+// (largest float below the acceptance threshold, index -1 = 0xffffffff): a candidate is then taken iff d2 < threshold,
+// strictly (search_start below).
 // TRACK: hit.lb2 follows the smallest squared distance among the examined candidates that did not end up as the
 // best (a displaced best included); the best itself, met again, is not "another point".
+__device__ __forceinline__ unsigned long long hit_key(float d2, int j) { return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)j; }
+
+__device__ __forceinline__ float search_start(float thr) { return thr > 0.0f ? __uint_as_float(__float_as_uint(thr) - 1u) : -1.0f; }
+
 template <bool WINDOW, bool TRACK = false>
 __device__ __forceinline__ void consider(const SfWindow &w, float px, float py, float pz, int j, bool valid, float qx, float qy, float qz, NNHit &hit)
 {
     const float d2 = l2_simple(qx, qy, qz, px, py, pz);
-    const bool better = d2 < hit.d2 || (d2 == hit.d2 && hit.j >= 0 && j < hit.j);
-    const bool take = valid && better && (!WINDOW || window_accepts(w, px, py, pz));
+    const bool take = valid && hit_key(d2, j) < hit_key(hit.d2, hit.j) && (!WINDOW || window_accepts(w, px, py, pz));
     if (TRACK && valid && j != hit.j) hit.lb2 = fminf(hit.lb2, take ? hit.d2 : d2);
     if (take) {
         hit.d2 = d2;
@@ -305,7 +310,7 @@ template <bool WINDOW>
 __device__ __forceinline__ NNHit nn_search(const SfGrid &g, const SfWindow &w, float qx, float qy, float qz, float thr)
 {
     NNHit hit;
-    hit.d2 = thr;
+    hit.d2 = search_start(thr);
     hit.j = -1;
     hit.px = hit.py = hit.pz = 0.0f;
     hit.lb2 = 0.0f;
@@ -397,7 +402,7 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
     const int lane = (int)__lane_id();
     const int nx = g.dim[0], ny = g.dim[1], nz = g.dim[2];
     NNHit hit;
-    hit.d2 = thr;
+    hit.d2 = search_start(thr);
     hit.j = -1;
     hit.px = hit.py = hit.pz = 0.0f;
     hit.lb2 = 3.0e38f;

@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
-"""profiles/<round>_traffic.json from the request-size PMC summaries (tools/profile_round.sh).
-usage: make_traffic_json.py profiles/r01 <scans in flight>"""
+"""profiles/<prefix>_traffic.json from the PMC summaries of tools/profile_round.sh: memory-side traffic of the dominant
+kernel by request size, and its vector-issue figures.
+usage: make_traffic_json.py profiles/r02 <scans in flight> <mode> <iters> <reuse|noreuse>"""
 import json
 import sys
 
 prefix = sys.argv[1]
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+mode = sys.argv[3] if len(sys.argv) > 3 else "p2plane"
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+reuse = (sys.argv[5] if len(sys.argv) > 5 else "reuse") == "reuse"
+kname = "k_ref_nn" if mode == "ref_cpp" else "k_nn_red"
 rd = json.load(open(prefix + "_rdsz_pmc.json"))
 wr = json.load(open(prefix + "_wrsz_pmc.json"))
-key = max((k for k in rd if k.startswith("k_nn_red")), key=lambda k: rd[k]["TCC_EA0_RDREQ_sum"]["avg"])   # the batched launches
+key = max((k for k in rd if k.startswith(kname)), key=lambda k: rd[k]["TCC_EA0_RDREQ_sum"]["avg"])   # the batched launches
 r, w = rd[key], wr[key]
 n32, n64, n128, nall = (r["TCC_EA0_RDREQ_%s" % s]["avg"] for s in ("32B_sum", "64B_sum", "128B_sum", "sum"))
 other = nall - n32 - n64 - n128
@@ -16,21 +21,38 @@ read_b = 32 * n32 + 64 * n64 + 128 * n128 + 64 * max(other, 0.0)
 w64, wall = w["TCC_EA0_WRREQ_64B_sum"]["avg"], w["TCC_EA0_WRREQ_sum"]["avg"]
 write_b = 64 * w64 + 32 * max(wall - w64, 0.0)
 q = 200000 * batch
+valu = None
+try:
+    sq = json.load(open(prefix + "_sq_pmc.json"))[key]
+    sq2 = json.load(open(prefix + "_sq2_pmc.json"))[key]
+    waves = sq["SQ_WAVES"]["avg"]
+    cycles = sq2["GRBM_GUI_ACTIVE"]["avg"] / 8.0                       # rocprofv3 sums the 8 XCDs
+    n_simd = 1024
+    util = sq2["SQ_ACTIVE_INST_VALU"]["avg"] * 4.0 / (n_simd * cycles)  # SQ_ACTIVE_INST_* count quad-cycles
+    valu = {"valu_instructions_per_wave": sq["SQ_INSTS_VALU"]["avg"] / waves, "salu_instructions_per_wave": sq["SQ_INSTS_SALU"]["avg"] / waves,
+            "vmem_read_instructions_per_wave": sq["SQ_INSTS_VMEM_RD"]["avg"] / waves, "lds_instructions_per_wave": sq["SQ_INSTS_LDS"]["avg"] / waves,
+            "waves_per_launch": waves, "kernel_cycles": cycles,
+            "valu_busy_frac": util,
+            "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): the share of the SIMDs' cycles spent issuing "
+                    "vector instructions, averaged over the launches of an alignment -- the roofline that binds a searching launch"}
+except (OSError, KeyError):
+    pass
 out = {
     "kernel": key.split(" grid=")[0],
-    "config": {"scan_points": 200000, "map_points": 10000000, "batch": batch, "iters": 20, "mode": "p2plane"},
+    "config": {"scan_points": 200000, "map_points": 10000000, "batch": batch, "iters": iters, "mode": mode, "nn_reuse": reuse},
     "queries_per_launch": q,
     "read_requests_per_launch": {"32B": n32, "64B": n64, "128B": n128, "all": nall},
     "read_bytes_per_launch": read_b,
     "write_bytes_per_launch": write_b,
     "traffic_bytes_per_launch": read_b + write_b,
     "traffic_bytes_per_query": (read_b + write_b) / q,
+    "valu": valu,
     "method": "rocprofv3 --pmc TCC_EA0_RDREQ_{sum,32B,64B,128B}_sum and TCC_EA0_WRREQ_{sum,64B}_sum in separate passes (no tracing flags) on "
-              "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph`; bytes = sum(requests x request size), averaged over the "
-              "batched k_nn_red launches. Practically all read requests are 128-byte requests, so FETCH_SIZE (requests x 64 B) under-reports this "
+              "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-extras [...]`; bytes = sum(requests x request size), averaged over the "
+              "batched launches of the kernel. Practically all read requests are 128-byte requests, so FETCH_SIZE (requests x 64 B) under-reports this "
               "kernel by the factor 2 that MI355X_MICROARCH.md (HBM section) gives for gfx950; WRITE_SIZE is exact. These are the memory-side "
               "requests of the L2 (Infinity-Cache hits included).",
-    "source": [prefix + s for s in ("_rdsz_pmc.json", "_wrsz_pmc.json", "_fetch_pmc.json", "_write_pmc.json")],
+    "source": [prefix + s for s in ("_rdsz_pmc.json", "_wrsz_pmc.json", "_fetch_pmc.json", "_write_pmc.json", "_sq_pmc.json", "_sq2_pmc.json")],
 }
 json.dump(out, open(prefix + "_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
