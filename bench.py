@@ -160,8 +160,15 @@ def main():
     else:
         def make_comm(lo, hi):
             """C-side RCCL communicator of the ranks lo..hi (every member calls this in the same order)."""
-            ident = [api.Comm.unique_id() if rank == lo else None]
+            ident = [None]
+            if rank == lo:
+                try:                               # whatever happens here, the broadcast below must still take place
+                    ident = [api.Comm.unique_id()]
+                except Exception as e:             # noqa: BLE001
+                    print("rank %d: ncclGetUniqueId failed: %s" % (rank, e), file=sys.stderr)
             dist.broadcast_object_list(ident, src=lo, group=groups[(lo, hi)] if (lo, hi) in groups else None)
+            if ident[0] is None:
+                raise RuntimeError("no RCCL unique id for ranks %d..%d" % (lo, hi))
             return api.Comm(ctx, hi - lo + 1, rank - lo, ident[0])
 
         groups = {}

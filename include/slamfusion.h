@@ -228,6 +228,10 @@ int sf_icp_align_batch(sf_icp *icp, int mode, sf_icp_result *out /* batch entrie
 int sf_icp_align_batch_async(sf_icp *icp, int mode);
 int sf_icp_fetch_results(sf_icp *icp, sf_icp_result *out);
 int sf_icp_use_graph(sf_icp *icp, int on); /* replay the launch sequence as a hipGraph */
+/* how often the launch sequence was captured / launched as a graph since creation (a capture per alignment means the
+ * cache key keeps changing).  REF_CPP with ONE scan reads the scan's point count and the map window from device memory,
+ * so scans of similar size (same count rounded up to 4096) and a moving window replay the same graph. */
+int sf_icp_graph_counts(sf_icp *icp, int64_t *captures, int64_t *launches);
 /* Order in which the points of a scan are walked by O3D_P2P / P2PLANE.  The correspondences and
  * every per-point term are independent of it; only the rounding of the record sums changes
  * (deterministically for a given order).  CELL sorts each scan by the map-grid cell of its points

@@ -472,6 +472,11 @@ class Icp:
     def use_graph(self, on=True):
         _check(self.lib.sf_icp_use_graph(self.h, C.c_int(int(on))))
 
+    def graph_counts(self):
+        a, b = C.c_int64(), C.c_int64()
+        _check(self.lib.sf_icp_graph_counts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_nn_reuse(self, on=True):
         _check(self.lib.sf_icp_set_nn_reuse(self.h, C.c_int(int(on))))
 

@@ -145,6 +145,7 @@ struct SfGrid {
 struct sf_map {
     sf_ctx *ctx = nullptr;
     sf::DevBuf pts4, nrm4, cell_start, keys, vals, keys2, vals2, inv_perm;
+    sf::DevBuf d_window; // the window in device memory (REF_CPP kernels read it there: a captured launch list survives a moving crop)
     sf::DevBuf cov6;   // optional: the 6 unique entries of each point's neighbourhood covariance (sorted order), sf_map_estimate_normals
     int64_t n = 0;
     bool built = false, has_normals = false, has_cov = false;

@@ -1004,11 +1004,17 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
 
 // ------------------------------------------------------------------ REF_CPP mode
 // X <- init * X0 in float32, unfused, exactly icp_point_to_point.cpp:99-110,191-192
-__global__ void k_ref_init(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n, const IcpState *__restrict__ st,
-                           float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz, int32_t *__restrict__ corr)
+// n_live (single-scan alignments): the scan's point count read from device memory, so that a captured launch list
+// stays valid while the count changes from scan to scan (the grid is sized for a rounded-up capacity); nullptr: n itself
+__global__ void k_set_int(int *__restrict__ p, int v) { *p = v; }
+__global__ void k_set_window(SfWindow *__restrict__ p, SfWindow w) { *p = w; }
+
+__global__ void k_ref_init(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n, const int *__restrict__ n_live,
+                           const IcpState *__restrict__ st, float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz, int32_t *__restrict__ corr)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_live) n = *n_live;
     if (i >= n) return;
     const IcpState *S = st + b;
     float T[12];
@@ -1028,9 +1034,14 @@ __global__ void k_ref_init(const float *__restrict__ X0x, const float *__restric
 // workgroups are placed like k_nn_red's: each XCD sweeps a contiguous eighth of the (cell-ordered) chunks for all scans
 // in flight.  grid.x is padded to a multiple of 8.
 template <bool WINDOW>
-__global__ __launch_bounds__(BLK) void k_ref_nn(SfGrid g, SfWindow w, const float *__restrict__ Xx, const float *__restrict__ Xy, const float *__restrict__ Xz, int n,
-                                                const IcpState *__restrict__ st, float thr, int force, int32_t *__restrict__ corr, int nblocks)
+__global__ __launch_bounds__(BLK) void k_ref_nn(SfGrid g, const SfWindow *__restrict__ wdev, const float *__restrict__ Xx, const float *__restrict__ Xy,
+                                                const float *__restrict__ Xz, int n, const int *__restrict__ n_live, const IcpState *__restrict__ st, float thr, int force,
+                                                int32_t *__restrict__ corr, int nblocks)
 {
+    SfWindow w;
+    if (WINDOW) w = *wdev; // the map crop lives in device memory: it moves with the pose, a captured launch list does not
+    else w.kind = 0;
+    if (n_live) n = *n_live;
     const int L = blockIdx.y * gridDim.x + blockIdx.x;
     const int kk = L >> 3;
     const int b = kk % (int)gridDim.y;
@@ -1051,9 +1062,10 @@ __global__ __launch_bounds__(BLK) void k_ref_nn(SfGrid g, SfWindow w, const floa
 // live pairs: n, sum s, sum t, sum s t^T, sum ||s - t|| (float32 norm, as
 // calculateErrorMetric icp_point_to_point.cpp:161-170 computes it per pair)
 __global__ __launch_bounds__(BLK) void k_ref_red(const float4 *__restrict__ pts, float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz, int n,
-                                                 const IcpState *__restrict__ st, const int32_t *__restrict__ corr, int apply_step, int only_if_research,
-                                                 double *__restrict__ partials, int nblocks)
+                                                 const int *__restrict__ n_live, const IcpState *__restrict__ st, const int32_t *__restrict__ corr, int apply_step,
+                                                 int only_if_research, double *__restrict__ partials, int nblocks)
 {
+    if (n_live) n = *n_live;
     const int b = blockIdx.y;
     const IcpState *S = st + b;
     if (S->done) return;
@@ -1169,6 +1181,9 @@ struct sf_icp {
     bool ordered = false;    // this alignment reads Xq
     sf::DevBuf corr;         // int32 [B*n] (REF_CPP)
     int64_t n = 0;           // points per scan
+    int64_t n_cap = 0;       // single scan: n rounded up (launch geometry of the REF_CPP kernels)
+    int64_t plane = 0;       // component stride of the SoA arrays X0 / X / Xq
+    sf::DevBuf n_dev;        // the point count in device memory (single-scan REF_CPP kernels read it)
     int batch = 0;
     std::vector<double> inits; // batch * 16
     std::vector<double> inits_uploaded; // what d_inits holds (the copy is skipped while nothing changed)
@@ -1203,6 +1218,7 @@ struct sf_icp {
     // graph
     bool use_graph = false;
     hipGraphExec_t graph_exec = nullptr;
+    int64_t graph_captures = 0, graph_replays = 0; // sf_icp_graph_counts
     // everything a captured launch list bakes in: kernel arguments passed by value (thresholds, IcpParams, the
     // SfGrid geometry and pointers) and the addresses of this object's buffers.  A replay is only valid while all of
     // it is unchanged; sf_map stamps every build / normals pass with a process-unique generation, DevBuf counts its
@@ -1238,7 +1254,7 @@ float *soa(sf::DevBuf &b, int64_t total, int axis) { return b.as<float>() + (siz
 const float *src(sf_icp *icp, int axis)
 {
     if (icp->shard) return soa(icp->Xq, icp->own_total, axis); // compact, cell-ordered owned queries (shard_build)
-    return soa(icp->ordered ? icp->Xq : icp->X0, icp->n * icp->batch, axis);
+    return soa(icp->ordered ? icp->Xq : icp->X0, icp->plane, axis);
 }
 
 // AUTO orders when there is enough work for the order to pay for the sort.  Measured, 200 k-point
@@ -1279,11 +1295,12 @@ int run_order_sort(sf_icp *icp, int nseg, int64_t longest, int64_t total, const 
     src.tiles = (int)std::max<int64_t>(1, sf::div_up(longest, sf::ORD_TILE));
     CellKeyFn kf;
     kf.g = g;
-    kf.x = soa(icp->X0, all, 0); kf.y = soa(icp->X0, all, 1); kf.z = soa(icp->X0, all, 2);
+    kf.x = soa(icp->X0, icp->plane, 0); kf.y = soa(icp->X0, icp->plane, 1); kf.z = soa(icp->X0, icp->plane, 2);
+    (void)all;
     kf.st = icp->state.as<IcpState>();
     kf.shift = order_key_shift(g);
     const size_t cap = (size_t)std::max<int64_t>(total, 1);
-    SF_TRY(icp->Xq.reserve(sizeof(float) * 3 * cap));
+    SF_TRY(icp->Xq.reserve(sizeof(float) * 3 * std::max(cap, (size_t)(seg_off ? 0 : icp->plane))));
     SF_TRY(icp->qkeys.reserve(sizeof(uint16_t) * cap));                                                      // bucket key of every element
     SF_TRY(icp->qkeys2.reserve(sizeof(uint32_t) * (size_t)nseg * (size_t)(src.tiles + 1) * sf::ORD_BINS));  // per-tile bucket counts / starts
     SF_TRY(icp->qidx.reserve(sizeof(uint32_t) * cap));                                                       // ordered query ids
@@ -1294,8 +1311,9 @@ int run_order_sort(sf_icp *icp, int nseg, int64_t longest, int64_t total, const 
     hipLaunchKernelGGL(k_order_hist, grid, blk, 0, s, src, kf, keys, counts);
     hipLaunchKernelGGL(sf::k_order_scan, dim3((unsigned)nseg), dim3(sf::ORD_BINS), 0, s, counts, src.tiles);
     hipLaunchKernelGGL(k_order_scatter, grid, blk, 0, s, src, keys, counts, ordered);
-    hipLaunchKernelGGL(k_order_gather, dim3(nblk(total, 256 * GATHER_PER_LANE)), dim3(256), 0, s, icp->X0r.as<float4>(), ordered, total, soa(icp->Xq, total, 0),
-                       soa(icp->Xq, total, 1), soa(icp->Xq, total, 2));
+    const int64_t qplane = seg_off ? total : icp->plane; // sharded: the compact arrays have their own length
+    hipLaunchKernelGGL(k_order_gather, dim3(nblk(total, 256 * GATHER_PER_LANE)), dim3(256), 0, s, icp->X0r.as<float4>(), ordered, total, soa(icp->Xq, qplane, 0),
+                       soa(icp->Xq, qplane, 1), soa(icp->Xq, qplane, 2));
     SF_HIP(hipGetLastError());
     return SF_OK;
 }
@@ -1314,11 +1332,17 @@ int order_queries(sf_icp *icp, int mode)
 int icp_alloc(sf_icp *icp, int64_t n, int batch)
 {
     const int64_t total = n * batch;
-    SF_TRY(icp->X0.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
-    SF_TRY(icp->X0r.reserve(sizeof(float4) * (size_t)std::max<int64_t>(total, 1)));
+    // plane = distance between the x, y and z components of the SoA arrays: rounded up and never shrinking, so that the
+    // component pointers a captured launch list holds survive scans of slightly different sizes
+    icp->plane = std::max<int64_t>(icp->plane, sf::div_up(std::max<int64_t>(total, 1), 4096) * 4096);
+    SF_TRY(icp->X0.reserve(sizeof(float) * 3 * (size_t)icp->plane));
+    SF_TRY(icp->X0r.reserve(sizeof(float4) * (size_t)icp->plane));
     SF_TRY(icp->state.reserve(sizeof(IcpState) * (size_t)batch));
     SF_TRY(icp->d_inits.reserve(sizeof(double) * 16 * (size_t)batch));
-    icp->nblocks = (int)std::max<int64_t>(1, sf::div_up(n, BLK));
+    // single scan: workgroups for the point count rounded up to 4096 (the kernels bound themselves by the count in
+    // device memory), so the launch geometry -- and with it a captured graph -- is shared by scans of similar size
+    icp->n_cap = batch == 1 ? sf::div_up(std::max<int64_t>(n, 1), 4096) * 4096 : n;
+    icp->nblocks = (int)std::max<int64_t>(1, sf::div_up(icp->n_cap, BLK));
     icp->nblocks_nn = (int)std::max<int64_t>(1, sf::div_up(n, BLK * QPL));
     SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)REC_STRIDE * (size_t)icp->nblocks * (size_t)batch));
     SF_TRY(icp->xchg_own.reserve(sizeof(double) * REC_STRIDE * (size_t)batch));
@@ -1338,8 +1362,10 @@ int icp_set_source_device_aos(sf_icp *icp, const float *d_aos, int64_t n, int ba
     SF_TRY(icp_alloc(icp, n, batch));
     const int64_t total = n * batch;
     if (total > 0)
-        hipLaunchKernelGGL(k_soa_from_aos, dim3(nblk(total)), dim3(256), 0, icp->ctx->stream, d_aos, total, soa(icp->X0, total, 0), soa(icp->X0, total, 1),
-                           soa(icp->X0, total, 2), icp->X0r.as<float4>());
+        hipLaunchKernelGGL(k_soa_from_aos, dim3(nblk(total)), dim3(256), 0, icp->ctx->stream, d_aos, total, soa(icp->X0, icp->plane, 0), soa(icp->X0, icp->plane, 1),
+                           soa(icp->X0, icp->plane, 2), icp->X0r.as<float4>());
+    SF_TRY(icp->n_dev.reserve(sizeof(int)));
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, icp->ctx->stream, icp->n_dev.as<int>(), (int)n);
     SF_HIP(hipGetLastError());
     // bounding box of the batch (the sharded path's list-rebuild rule reads it in k_solve_only): reduced on the
     // device and left there -- no host synchronisation per scan
@@ -1385,12 +1411,13 @@ sf_icp::GraphKey graph_key_now(const sf_icp *icp, int mode)
 {
     sf_icp::GraphKey k;
     k.mode = mode; k.iters = icp->prm.num_iters; k.batch = icp->batch; k.window = icp->map->window.kind; k.ordered = (int)icp->ordered; k.reuse = (int)icp->reuse;
-    k.n = icp->n;
+    k.n = (mode == SF_ICP_REF_CPP && icp->batch == 1) ? -icp->n_cap : icp->n; // REF_CPP, one scan: any count of the same capacity replays
     k.map = (const void *)icp->map;
     k.map_generation = icp->map->generation;
     k.max_corr = icp->prm.max_corr; k.accept = icp->prm.accept; k.eps = icp->prm.eps;
-    const sf::DevBuf *bufs[] = {&icp->X0, &icp->X0r, &icp->X, &icp->Xq, &icp->qcache, &icp->corr, &icp->state, &icp->partials, &icp->d_box,
-                                &icp->map->pts4, &icp->map->nrm4, &icp->map->cell_start};
+    const sf::DevBuf *bufs[] = {&icp->X0, &icp->X0r, &icp->X, &icp->Xq, &icp->qcache, &icp->corr, &icp->state, &icp->partials, &icp->d_box, &icp->n_dev,
+                                &icp->map->pts4, &icp->map->nrm4, &icp->map->cell_start, &icp->map->d_window};
+    k.epochs = (uint64_t)icp->plane;
     for (const sf::DevBuf *b : bufs) k.epochs = k.epochs * 1000003ull + b->epoch;
     return k;
 }
@@ -1477,25 +1504,25 @@ int enqueue_align(sf_icp *icp, int mode)
             hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K);
         }
     } else {
-        const int64_t total = icp->n * B;
-        SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
-        SF_TRY(icp->corr.reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1)));
-        float *Xx = soa(icp->X, total, 0), *Xy = soa(icp->X, total, 1), *Xz = soa(icp->X, total, 2);
+        SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(icp->plane, 1)));
+        SF_TRY(icp->corr.reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(icp->plane, 1)));
+        float *Xx = soa(icp->X, icp->plane, 0), *Xy = soa(icp->X, icp->plane, 1), *Xz = soa(icp->X, icp->plane, 2);
         int32_t *corr = icp->corr.as<int32_t>();
-        const dim3 gpts(nblk(n), (unsigned)B), gred((unsigned)icp->nblocks, (unsigned)B);
+        const dim3 gpts((unsigned)icp->nblocks, (unsigned)B), gred((unsigned)icp->nblocks, (unsigned)B);
+        const int *nl = B == 1 ? icp->n_dev.as<int>() : nullptr; // single scan: the count comes from the device (see k_ref_init)
         const bool win = m->window.kind != 0;
         const float thr = icp->prm.max_corr; // squared-vs-unsquared quirk, icp_point_to_point.cpp:70
         const dim3 gnn((unsigned)((icp->nblocks + 7) & ~7), (unsigned)B); // see the XCD mapping in k_ref_nn
         auto nn = [&](int force) {
             ProfScope ps(icp);
-            if (win) hipLaunchKernelGGL(k_ref_nn<true>, gnn, dim3(BLK), 0, s, m->grid, m->window, Xx, Xy, Xz, n, st, thr, force, corr, icp->nblocks);
-            else hipLaunchKernelGGL(k_ref_nn<false>, gnn, dim3(BLK), 0, s, m->grid, m->window, Xx, Xy, Xz, n, st, thr, force, corr, icp->nblocks);
+            if (win) hipLaunchKernelGGL(k_ref_nn<true>, gnn, dim3(BLK), 0, s, m->grid, m->d_window.as<SfWindow>(), Xx, Xy, Xz, n, nl, st, thr, force, corr, icp->nblocks);
+            else hipLaunchKernelGGL(k_ref_nn<false>, gnn, dim3(BLK), 0, s, m->grid, (const SfWindow *)nullptr, Xx, Xy, Xz, n, nl, st, thr, force, corr, icp->nblocks);
         };
         auto red = [&](int apply, int only_research) {
-            hipLaunchKernelGGL(k_ref_red, gred, dim3(BLK), 0, s, m->grid.pts, Xx, Xy, Xz, n, st, corr, apply, only_research, part, icp->nblocks);
+            hipLaunchKernelGGL(k_ref_red, gred, dim3(BLK), 0, s, m->grid.pts, Xx, Xy, Xz, n, nl, st, corr, apply, only_research, part, icp->nblocks);
         };
         auto decide = [&](int phase) { hipLaunchKernelGGL(k_ref_decide, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks, icp->prm, phase); };
-        hipLaunchKernelGGL(k_ref_init, gpts, dim3(BLK), 0, s, src(icp, 0), src(icp, 1), src(icp, 2), n, st, Xx, Xy, Xz, corr); // the cell-ordered copy when ordering is on
+        hipLaunchKernelGGL(k_ref_init, gpts, dim3(BLK), 0, s, src(icp, 0), src(icp, 1), src(icp, 2), n, nl, st, Xx, Xy, Xz, corr); // the cell-ordered copy when ordering is on
         nn(1);
         red(0, 0);
         decide(0);
@@ -1581,7 +1608,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     if (icp->inits_ev) { e = hipEventDestroy(icp->inits_ev); (void)e; }
     if (icp->h_inits) { e = hipHostFree(icp->h_inits); (void)e; }
     icp->X0.release(); icp->X0r.release(); icp->qcache.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
-    icp->nn_stats.release(); icp->d_box.release(); icp->stage.release(); icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
+    icp->n_dev.release(); icp->nn_stats.release(); icp->d_box.release(); icp->stage.release(); icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
     sf_ctx *ctx = icp->ctx;
@@ -1691,6 +1718,14 @@ extern "C" int sf_icp_set_nn_reuse(sf_icp *icp, int on)
     return SF_OK;
 }
 
+extern "C" int sf_icp_graph_counts(sf_icp *icp, int64_t *captures, int64_t *launches)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    if (captures) *captures = icp->graph_captures;
+    if (launches) *launches = icp->graph_replays;
+    return SF_OK;
+}
+
 extern "C" int sf_icp_use_graph(sf_icp *icp, int on)
 {
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
@@ -1706,13 +1741,17 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     hipStream_t s = icp->ctx->stream;
     icp->last_mode = mode;
     SF_TRY(launch_state_init(icp));
+    if (mode == SF_ICP_REF_CPP && icp->map->window.kind != 0) { // the map crop as it stands now, for the kernels that read it from the device
+        SF_TRY(icp->map->d_window.reserve(sizeof(SfWindow)));
+        hipLaunchKernelGGL(k_set_window, dim3(1), dim3(1), 0, s, icp->map->d_window.as<SfWindow>(), icp->map->window);
+    }
     SF_TRY(order_queries(icp, mode)); // plain launches ahead of the (replayed) iteration graph
     if (mode != SF_ICP_REF_CPP) SF_TRY(reuse_reset(icp, icp->n * icp->batch));
-    if (icp->use_graph && !icp->profiling && icp->map->window.kind == 0) { // a window travels by value and moves with the pose: plain launches
+    // O3D_P2P / P2PLANE take the window by value (it moves with the pose: plain launches then); REF_CPP reads it from device memory
+    if (icp->use_graph && !icp->profiling && (icp->map->window.kind == 0 || mode == SF_ICP_REF_CPP)) {
         if (mode == SF_ICP_REF_CPP) { // buffers must exist before capture (and before the key is formed)
-            const int64_t total = icp->n * icp->batch;
-            SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
-            SF_TRY(icp->corr.reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1)));
+            SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(icp->plane, 1)));
+            SF_TRY(icp->corr.reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(icp->plane, 1)));
         }
         const sf_icp::GraphKey key = graph_key_now(icp, mode);
         const bool hit = icp->graph_exec && key == icp->graph_key;
@@ -1729,7 +1768,9 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
             (void)e2;
             SF_CHECK(e == hipSuccess, SF_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
             icp->graph_key = key;
+            icp->graph_captures += 1;
         }
+        icp->graph_replays += 1;
         SF_HIP(hipGraphLaunch(icp->graph_exec, s));
         return SF_OK;
     }
@@ -1811,14 +1852,13 @@ int shard_build(sf_icp *icp, bool resume)
 {
     const int B = icp->batch;
     const int n = (int)icp->n;
-    const int64_t total = icp->n * B;
     const int nbf = icp->nblocks; // workgroups covering a whole scan
     hipStream_t s = icp->ctx->stream;
     IcpState *st = icp->state.as<IcpState>();
     SF_TRY(icp->own_blk.reserve(sizeof(uint32_t) * (size_t)nbf * (size_t)B));
     SF_TRY(icp->own_count.reserve(sizeof(uint32_t) * (size_t)B));
     SF_TRY(icp->own_off.reserve(sizeof(uint32_t) * (size_t)(B + 1)));
-    const float *X = soa(icp->X0, total, 0), *Y = soa(icp->X0, total, 1), *Z = soa(icp->X0, total, 2);
+    const float *X = soa(icp->X0, icp->plane, 0), *Y = soa(icp->X0, icp->plane, 1), *Z = soa(icp->X0, icp->plane, 2);
     const dim3 grid((unsigned)nbf, (unsigned)B);
     if (resume) hipLaunchKernelGGL(k_own_resume, dim3(nblk(B, 64)), dim3(64), 0, s, st, B);
     hipLaunchKernelGGL(k_own_count, grid, dim3(BLK), 0, s, X, Y, Z, n, st, icp->xlo, icp->xhi, icp->own_margin, icp->own_blk.as<uint32_t>(), nbf);

@@ -98,7 +98,7 @@ extern "C" void sf_map_destroy(sf_map *m)
     if (!m) return;
     hipError_t e = hipStreamSynchronize(m->ctx->stream);
     (void)e;
-    m->pts4.release(); m->nrm4.release(); m->cov6.release(); m->cell_start.release(); m->keys.release(); m->vals.release();
+    m->pts4.release(); m->nrm4.release(); m->cov6.release(); m->d_window.release(); m->cell_start.release(); m->keys.release(); m->vals.release();
     m->keys2.release(); m->vals2.release(); m->inv_perm.release();
     sf_ctx *ctx = m->ctx;
     delete m;

@@ -37,6 +37,9 @@ class LocalizationFlow:
         self.altitude_table_ = np.zeros((0, 3)) if altitude_table is None else np.asarray(altitude_table, dtype=np.float64)
         self.icp_ = api.Icp(ctx, 0.5, 10, 0.05, 1e-5)        # :24-28
         self.icp_.set_target(self.map_index_)
+        # the alignment's ~50 small launches replayed as one hipGraph: the scan's point count and the map crop are read from
+        # device memory by the REF_CPP kernels, so the captured list survives both changing from scan to scan
+        self.icp_.use_graph(True)
         self.coarse_pose_filter_ = api.StochasticFilter(4, 3.0)   # :32-34
         self.brute_force_alignment_ = api.BruteForceAlignment(ctx)   # :38-43
         self.brute_force_alignment_.setMeanErrorThreshold(0.1)

@@ -170,3 +170,39 @@ def test_per_scan_preprocessing_reuses_buffers(api, ctx, orc, small_world):
         exp2 = orc.remove_floor(exp)
         c.remove_floor()
         assert np.array_equal(c.download(), exp2)
+
+
+def test_single_scan_ref_cpp_graph_survives_changing_counts_and_windows(api, ctx, orc, synth, small_world):
+    """The per-scan path: REF_CPP with ONE scan reads the scan's point count and the map window from device memory, so
+    one captured launch list serves a stream of scans whose sizes differ (same count rounded up to 4096) while the
+    window moves -- and every result equals the plain-launch alignment bit for bit, and the oracle's."""
+    m = small_world["map"]
+    mp = api.Map(ctx, api.Cloud(ctx, m), 0.25)
+    g = api.Icp(ctx, 0.5, 10, 0.001, 1e-5)
+    p = api.Icp(ctx, 0.5, 10, 0.001, 1e-5)
+    for icp in (g, p):
+        icp.set_target(mp)
+    g.use_graph(True)
+    rng = np.random.default_rng(8)
+    for k, n in enumerate((9000, 8700, 9500, 8200, 9900)):
+        scan = synth.make_scan(m, n, scan_id=30 + k)[0]
+        center = np.array([0.3 * k - 0.5, 0.2 * k, 0.0], np.float32)
+        mp.window_sphere(center, 4.0 + 0.1 * k)
+        init = synth.make_T(rng.normal(0, 0.01, 3), rng.normal(0, 0.05, 3)).astype(np.float32)
+        res = []
+        for icp in (g, p):
+            icp.set_source(scan)
+            icp.set_initial_transformation(init)
+            res.append(icp.align("ref_cpp"))
+        a, b = res
+        assert np.array_equal(a["T64"], b["T64"]) and a["iterations"] == b["iterations"] and a["n_corr"] == b["n_corr"] and a["error"] == b["error"]
+        crop, _ = orc.crop_radius(m, center, 4.0 + 0.1 * k)
+        o = orc.icp_ref_cpp(scan, crop, init, 0.5, 10, 0.001, 1e-5, precise=True)
+        assert a["iterations"] == o["iterations"] and a["n_corr"] == o["n_corr"]
+        dt, dr = synth.pose_error(a["T64"], o["T"])
+        assert dt < 1e-4 and dr < 1e-5
+    captures, launches = g.graph_counts()
+    assert captures == 1 and launches == 5                     # 8 200 .. 9 900 points all round up to 12 288
+    g.set_source(synth.make_scan(m, 3000, scan_id=99)[0])      # another capacity class: one more capture
+    g.align("ref_cpp")
+    assert g.graph_counts() == (2, 6)

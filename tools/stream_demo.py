@@ -83,7 +83,8 @@ def main():
     print(json.dumps({"prior": args.prior, "scans": args.scans, "scan_points_raw": args.scan_points, "points_after_stride2_and_crop": flow.last["n_scan"],
                       "callback_ms_median": float(np.median(times) * 1e3), "callback_ms_p99": float(np.quantile(times, 0.99) * 1e3),
                       "scans_per_s": float(1.0 / np.mean(times)), "translation_err_m_median": float(np.median(errs)),
-                      "translation_err_m_max": float(np.max(errs)), "reference_budget_ms": 100.0}))
+                      "translation_err_m_max": float(np.max(errs)), "reference_budget_ms": 100.0,
+                      "graph_captures_and_launches": list(flow.icp_.graph_counts())}))
 
 
 if __name__ == "__main__":
