@@ -156,7 +156,8 @@ __device__ __forceinline__ void scan4(const SfGrid &g, const SfWindow &w, uint32
 }
 
 // CSR candidates [a, b).  (Eight loads in flight per trip instead of four: measured slower at 32 scans in flight --
-// 545 -> 609 us for a searching launch, 89 -> 94 us for a verifying one -- and no faster on the per-scan path.)
+// 545 -> 609 us for a searching launch, 89 -> 94 us for a verifying one -- and slower on the per-scan path too, even
+// when only the REF_CPP search was built that way: 404 -> 434 us per search at 32 in flight, callback 0.72 -> 0.76 ms.)
 template <bool WINDOW, bool TRACK = false>
 __device__ __forceinline__ void scan_range(const SfGrid &g, const SfWindow &w, uint32_t a, uint32_t b, float qx, float qy, float qz, NNHit &hit)
 {
