@@ -58,6 +58,20 @@ def main():
                         pl_T=r_pl["T"], pl_meta=np.array([r_pl["iterations"], r_pl["n_corr"]]), pl_rmse=r_pl["error"],
                         crop_radius_idx=crop_ri, crop_aabb_idx=crop_ai, crop_obb_idx=crop_oi, obb_R=Rb)
 
+    # ---- round-2 additions: int64 voxel grid past PCL's overflow, covariances of the normal estimation, brute-force scores
+    rng2 = np.random.Generator(np.random.PCG64(12))
+    far = np.concatenate([rng2.uniform(0, 1, (300, 3)), rng2.uniform(0, 1, (300, 3)) + [2500.0, 1800.0, 900.0]]).astype(np.float32)
+    far_ds, far_pid, far_oid = orc.voxel_pcl64(far, 0.1)
+    assert orc.voxel_pcl(far, 0.1)[3] == -1
+    _, _, cov6 = orc.normals_radius_cov(ds, float(np.float32(0.3)))
+    bf_T = synth.make_T((0.2, -0.1, 0.05), (0, 0, 10.0))
+    bf_scan, _ = synth.make_scan(ds, 300, scan_id=9, T=bf_T)
+    bf_prev = synth.make_T((0.01, 0.0, 0.0), (0, 0, 0.5)).astype(np.float32)
+    bf_prm = dict(x_step=0.1, y_step=0.1, z_step=0.05, yaw_step=np.pi / 18.0, x_range=0.3, y_range=0.3, z_range=0.1, yaw_range=np.pi / 6.0)
+    bf = orc.bf_align(bf_scan, ds, bf_prev, threshold=1e-9, **bf_prm)
+    np.savez_compressed(os.path.join(HERE, "extensions_small.npz"), far=far, far_ds=far_ds, far_point_ids=far_pid, far_out_ids=far_oid,
+                        cov6=cov6, bf_scan=bf_scan, bf_prev=bf_prev, bf_scores=bf["scores"], bf_best_T=bf["best_T"], bf_index=np.array([bf["index"], bf["n_candidates"]]))
+
     # ---- fusion vectors
     ll = np.array([[-22.9068, -43.1729], [48.8566, 2.3522], [59.9, 10.7], [0.0, 0.0], [-33.86, 151.21], [35.68, 139.69], [64.1, -21.9]])
     utm_ref = np.array([orc.ref_ll_to_utm(a, b) for a, b in ll]) if orc.ref_lib() is not None else np.array([orc.ll_to_utm(a, b) for a, b in ll])

@@ -30,3 +30,14 @@ def test_oracle_reproduces_golden_registration(orc, synth):
     # the golden registration itself recovers the generating transform
     dt, dr = synth.pose_error(g["o3d_T"], synth.t_true())
     assert dt < 5e-3 and dr < 2e-3
+
+
+def test_oracle_reproduces_golden_extensions(orc, synth):
+    g, e = load_golden("registration_small.npz"), load_golden("extensions_small.npz")
+    ds, pid, oid = orc.voxel_pcl64(e["far"], 0.1)
+    assert np.array_equal(ds, e["far_ds"]) and np.array_equal(pid, e["far_point_ids"]) and np.array_equal(oid, e["far_out_ids"]) and oid.max() > 2**31
+    _, _, cov = orc.normals_radius_cov(g["map"], float(np.float32(0.3)))
+    assert np.allclose(cov, e["cov6"], rtol=1e-12, atol=1e-18)
+    prm = dict(x_step=0.1, y_step=0.1, z_step=0.05, yaw_step=np.pi / 18.0, x_range=0.3, y_range=0.3, z_range=0.1, yaw_range=np.pi / 6.0)
+    bf = orc.bf_align(e["bf_scan"], g["map"], e["bf_prev"], threshold=1e-9, **prm)
+    assert np.array_equal(bf["scores"], e["bf_scores"]) and np.array_equal(bf["best_T"], e["bf_best_T"]) and [bf["index"], bf["n_candidates"]] == list(e["bf_index"])

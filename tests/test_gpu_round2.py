@@ -206,3 +206,28 @@ def test_single_scan_ref_cpp_graph_survives_changing_counts_and_windows(api, ctx
     g.set_source(synth.make_scan(m, 3000, scan_id=99)[0])      # another capacity class: one more capture
     g.align("ref_cpp")
     assert g.graph_counts() == (2, 6)
+
+
+def test_gpu_against_golden_extensions(api, ctx):
+    from conftest import load_golden
+    g, e = load_golden("registration_small.npz"), load_golden("extensions_small.npz")
+    c = api.Cloud(ctx, e["far"])
+    assert c.voxel_downsample(0.1, "pcl") == api.SF_FLAG_VOXEL_OVERFLOW
+    assert c.voxel_downsample(0.1, "pcl64") == 0
+    assert np.array_equal(c.download(), e["far_ds"]) and np.array_equal(c.voxel_point_ids64(), e["far_point_ids"]) and np.array_equal(c.voxel_out_ids64(), e["far_out_ids"])
+    mp = api.Map(ctx, api.Cloud(ctx, g["map"]), 0.25)
+    mp.estimate_normals(0.3, covariance=True)
+    assert np.abs(mp.download_covariances() - e["cov6"]).max() <= 1e-12 * np.abs(e["cov6"]).max()
+    bf = api.BruteForceAlignment(ctx)
+    bf.setXYZStep(0.1, 0.1, 0.05)
+    bf.setXYZRange(0.3, 0.3, 0.1)
+    bf.setRotationStep(np.pi / 18.0)
+    bf.setRotationRange(np.pi / 6.0)
+    bf.setMeanErrorThreshold(1e-9)
+    bf.setInitialGuess(e["bf_prev"])
+    bf.setSourceCloud(e["bf_scan"])
+    bf.setTargetCloud(mp)
+    assert not bf.alignClouds()
+    r = bf.last_result()
+    assert np.array_equal(r["scores"], e["bf_scores"]) and [r["index"], r["n_candidates"]] == list(e["bf_index"])   # serial float32 sums, bit for bit
+    assert np.array_equal(bf.getBestTransformation(), e["bf_best_T"])
