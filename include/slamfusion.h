@@ -185,6 +185,7 @@ typedef struct {
 } sf_icp_result;
 #define SF_ICP_FLAG_FEW_CORR 1   /* < 10 correspondences: reference returns the initial T */
 #define SF_ICP_FLAG_SINGULAR 2   /* p2plane normal equations not positive definite       */
+#define SF_ICP_FLAG_BARRIER_TIMEOUT 8 /* internal: a grid barrier of the single-launch REF_CPP form gave up; sf_icp_fetch_results turns it into SF_ERR_HIP */
 #define SF_ICP_FLAG_SHARD_STALE 4 /* sharded stepping: the scan moved out of the margin of this rank's owned-query arrays and stopped; resume with sf_icp_step_begin(first = 2) */
 
 /* modes: REF_CPP = ICPPointToPoint::calculateAlignment (icp_point_to_point.cpp:185-254,
@@ -232,6 +233,12 @@ int sf_icp_use_graph(sf_icp *icp, int on); /* replay the launch sequence as a hi
  * cache key keeps changing).  REF_CPP with ONE scan reads the scan's point count and the map window from device memory,
  * so scans of similar size (same count rounded up to 4096) and a moving window replay the same graph. */
 int sf_icp_graph_counts(sf_icp *icp, int64_t *captures, int64_t *launches);
+/* REF_CPP alignments small enough for every workgroup to be resident at once (the node's per-scan path: ~13 k points)
+ * run as ONE launch -- search, record, controller and step of icp_point_to_point.cpp:185-254 behind in-kernel grid
+ * barriers, bit-identical to the launch list; on by default, larger alignments and profiled ones take the launch list.
+ * sf_icp_fused_count: how many alignments have taken the single-launch form since creation. */
+int sf_icp_set_fused(sf_icp *icp, int on);
+int sf_icp_fused_count(sf_icp *icp, int64_t *launches);
 /* Order in which the points of a scan are walked by O3D_P2P / P2PLANE.  The correspondences and
  * every per-point term are independent of it; only the rounding of the record sums changes
  * (deterministically for a given order).  CELL sorts each scan by the map-grid cell of its points

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libslamfusion.so")
 SF_ICP_REF_CPP, SF_ICP_O3D_P2P, SF_ICP_P2PLANE = 0, 1, 2
 SF_VOXEL_PCL, SF_VOXEL_O3D, SF_VOXEL_PCL64 = 0, 1, 2
 SF_FLAG_VOXEL_OVERFLOW = 1
-SF_ICP_FLAG_FEW_CORR, SF_ICP_FLAG_SINGULAR, SF_ICP_FLAG_SHARD_STALE = 1, 2, 4
+SF_ICP_FLAG_FEW_CORR, SF_ICP_FLAG_SINGULAR, SF_ICP_FLAG_SHARD_STALE, SF_ICP_FLAG_BARRIER_TIMEOUT = 1, 2, 4, 8
 MODES = {"ref_cpp": SF_ICP_REF_CPP, "o3d_p2p": SF_ICP_O3D_P2P, "p2plane": SF_ICP_P2PLANE}
 
 
@@ -476,6 +476,14 @@ class Icp:
         a, b = C.c_int64(), C.c_int64()
         _check(self.lib.sf_icp_graph_counts(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def set_fused(self, on=True):
+        _check(self.lib.sf_icp_set_fused(self.h, C.c_int(int(on))))
+
+    def fused_count(self):
+        a = C.c_int64()
+        _check(self.lib.sf_icp_fused_count(self.h, C.byref(a)))
+        return a.value
 
     def set_nn_reuse(self, on=True):
         _check(self.lib.sf_icp_set_nn_reuse(self.h, C.c_int(int(on))))

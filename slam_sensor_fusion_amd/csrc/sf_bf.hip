@@ -66,7 +66,7 @@ __global__ __launch_bounds__(BLK, 4) void k_bf_score(SfGrid g, SfWindow w, const
         qy = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], x), __fmul_rn(T[5], y)), __fmul_rn(T[6], z)), T[7]);
         qz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], x), __fmul_rn(T[9], y)), __fmul_rn(T[10], z)), T[11]);
     }
-    const sf::NNHit hit = sf::nn_search_wave<WINDOW>(g, w, live, qx, qy, qz, 3.0e38f, &nn_ws[threadIdx.x >> 6]);
+    const sf::NNHit hit = sf::nn_search_wave<WINDOW, true>(g, w, live, qx, qy, qz, 3.0e38f, &nn_ws[threadIdx.x >> 6]);
     if (live) d2_out[(size_t)c * n + i] = hit.j >= 0 ? hit.d2 : 0.0f;
 }
 

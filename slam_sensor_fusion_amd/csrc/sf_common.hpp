@@ -99,6 +99,10 @@ struct sf_ctx {
     sf::DevBuf scratch;   // rocPRIM temporary storage
     sf::DevBuf scratch2;  // block counts / small reductions
     void *h_pinned = nullptr; // small pinned staging (4 KiB)
+    // pageable -> device uploads go through two pinned buffers in turn (sf::upload_staged): the runtime's own staging of
+    // a pageable hipMemcpyAsync moves ~5 GB/s and holds the host until the stream has reached the copy
+    struct Stage { void *p = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; } stage[2];
+    int stage_next = 0;
     int refs = 0;          // live clouds / maps / icps created on this context
     bool zombie = false;   // sf_ctx_destroy was called while children were alive
 };
@@ -163,6 +167,8 @@ sf_ctx *comm_ctx(const sf_comm *c);
 // device-side helpers implemented in sf_cloud.hip, used across TUs
 int compact_cloud(sf_cloud *c, const uint8_t *d_flags);
 int ensure_scratch(sf_ctx *ctx, size_t bytes);
+// dst (device) <- src (any host memory), stream-ordered on the context's stream; src may be freed on return
+int upload_staged(sf_ctx *ctx, void *dst, const void *src, size_t bytes);
 uint64_t next_generation();
 // children keep their context alive: any destruction order is safe
 void ctx_retain(sf_ctx *ctx);

@@ -371,22 +371,27 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NREC], double *
 // adds rows s, s+32, s+64, ... then the 32 slices are added in order.  Result in rec[]
 // (shared).  Deterministic: no atomics, the order depends only on nblocks.
 constexpr int RBLK = 1024;
-template <int NREC>
+// NT = threads of the calling workgroup (a multiple of 32, at most 1024): with fewer than 1024 a thread takes several
+// slices one after the other -- every (slice, component) sum is the same expression, so the result is bit-identical
+// for every NT.
+template <int NREC, int NT = RBLK>
 __device__ __forceinline__ void reduce_partials(const double *__restrict__ part, int nblocks, double *rec)
 {
     __shared__ double sl[32][REC_STRIDE + 1];
-    const int c = threadIdx.x & 31, sidx = threadIdx.x >> 5;
-    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-    if (c < NREC) {
-        int b = sidx;
-        for (; b + 96 < nblocks; b += 128) {
-            const double a0 = part[(size_t)b * REC_STRIDE + c], a1 = part[(size_t)(b + 32) * REC_STRIDE + c];
-            const double a2 = part[(size_t)(b + 64) * REC_STRIDE + c], a3 = part[(size_t)(b + 96) * REC_STRIDE + c];
-            v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+    const int c = threadIdx.x & 31;
+    for (int sidx = threadIdx.x >> 5; sidx < 32; sidx += NT / 32) {
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        if (c < NREC) {
+            int b = sidx;
+            for (; b + 96 < nblocks; b += 128) {
+                const double a0 = part[(size_t)b * REC_STRIDE + c], a1 = part[(size_t)(b + 32) * REC_STRIDE + c];
+                const double a2 = part[(size_t)(b + 64) * REC_STRIDE + c], a3 = part[(size_t)(b + 96) * REC_STRIDE + c];
+                v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+            }
+            for (; b < nblocks; b += 32) v0 += part[(size_t)b * REC_STRIDE + c];
         }
-        for (; b < nblocks; b += 32) v0 += part[(size_t)b * REC_STRIDE + c];
+        sl[sidx][c] = (v0 + v1) + (v2 + v3);
     }
-    sl[sidx][c] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (threadIdx.x < REC_STRIDE) {
         double v = 0;
@@ -1054,7 +1059,7 @@ __global__ __launch_bounds__(BLK) void k_ref_nn(SfGrid g, const SfWindow *__rest
     const size_t o = (size_t)b * n + (size_t)(i < n ? i : 0);
     const bool live = i < n && corr[o] >= 0;
     const float qx = live ? Xx[o] : 0.0f, qy = live ? Xy[o] : 0.0f, qz = live ? Xz[o] : 0.0f;
-    const sf::NNHit hit = sf::nn_search_wave<WINDOW>(g, w, live, qx, qy, qz, thr, &nn_ws[threadIdx.x >> 6]);
+    const sf::NNHit hit = sf::nn_search_wave<WINDOW, true>(g, w, live, qx, qy, qz, thr, &nn_ws[threadIdx.x >> 6]);
     if (live) corr[o] = hit.j;
 }
 
@@ -1128,16 +1133,9 @@ __device__ __forceinline__ void ref_take_step(IcpState *S, const double *rec, fl
 }
 
 // phase 0: after the initial search (cpp:195-200); phase 1: top of loop iteration
-// (cpp:209-224); phase 2: after a lazy re-search (cpp:223-226)
-__global__ __launch_bounds__(RBLK) void k_ref_decide(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, IcpParams prm, int phase)
+// (cpp:209-224); phase 2: after a lazy re-search (cpp:223-226).  One lane; rec = the record of the live pairs.
+__device__ __forceinline__ void ref_decide(IcpState *S, const double *rec, const IcpParams &prm, int phase)
 {
-    const int b = blockIdx.x;
-    IcpState *S = st + b;
-    if (S->done) return;
-    if (phase == 2 && !S->research) return;
-    __shared__ double rec[REC_STRIDE];
-    reduce_partials<NREC_P2P>(partials + (size_t)b * nblocks * REC_STRIDE, nblocks, rec);
-    if (threadIdx.x != 0) return;
     for (int c = 0; c < NREC_P2P; ++c) S->rec[c] = rec[c];
     const double n = rec[0];
     if (phase == 0) {
@@ -1161,6 +1159,181 @@ __global__ __launch_bounds__(RBLK) void k_ref_decide(IcpState *__restrict__ st, 
     S->n_research += 1;
     if (!(n >= 1)) { S->flags |= SF_ICP_FLAG_FEW_CORR; S->done = 1; return; }
     ref_take_step(S, rec, S->err_pending);
+}
+
+__global__ __launch_bounds__(RBLK) void k_ref_decide(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, IcpParams prm, int phase)
+{
+    const int b = blockIdx.x;
+    IcpState *S = st + b;
+    if (S->done) return;
+    if (phase == 2 && !S->research) return;
+    __shared__ double rec[REC_STRIDE];
+    reduce_partials<NREC_P2P>(partials + (size_t)b * nblocks * REC_STRIDE, nblocks, rec);
+    if (threadIdx.x != 0) return;
+    ref_decide(S, rec, prm, phase);
+}
+
+// ------------------------------------------------------------------ REF_CPP, the whole alignment in ONE launch
+// For scans small enough that every workgroup is resident at once (the per-scan path of the node: ~13 k points after the
+// stride-2 subsample and the 10 m crop = 64 workgroups) the 4 + 5 K - 1 launches above -- most of them returning at once
+// because their phase is not active, each still a launch and a dependent kernel boundary -- become one: a workgroup keeps
+// its 256 points, their correspondences and neighbours in registers from the first search to the last step, the record of
+// the live pairs goes through the same per-workgroup rows (block_reduce_store) and the same fixed-order sum
+// (reduce_partials) as above, and EVERY workgroup evaluates the controller (ref_decide) on its own copy of the state in
+// LDS: same inputs, same code, same decision everywhere, so all workgroups of a scan walk the same sequence of phases and
+// meet at the same grid barriers -- one per record, none for the decisions.  Results are bit-identical to the launch
+// list (tests/test_gpu_round2.py).
+// Grid barrier (per scan, workgroups of one scan only): a monotonic arrival counter.  Producer side: every wave drains
+// its stores, workgroup barrier, lane 0 agent-scope release fence + drain, agent-scope add.  Consumer side: lane 0 polls
+// with relaxed agent-scope loads (served by L2, not the CU's L1) and s_sleep, ONE agent-scope acquire fence + drain,
+// workgroup barrier, plain loads (MI355X: per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed
+// by another CU's stores -- workgroup scope is not enough).  Every spin is bounded (FUSED_SPIN_TICKS of the 100 MHz
+// clock): a workgroup that gives up raises SF_ICP_FLAG_BARRIER_TIMEOUT in the state and leaves, so the grid always
+// drains; the host turns the flag into an error.
+constexpr long long FUSED_SPIN_TICKS = 200000000; // 2 s
+#ifdef SF_FUSED_TRACE
+__device__ unsigned long long g_fused_trace[512];
+#define FTRACE(code) do { if (bx == 0 && b == 0 && threadIdx.x == 0 && tr_n < 511) g_fused_trace[1 + tr_n++] = ((unsigned long long)wall_clock64() << 8) | (unsigned)(code); } while (0)
+#else
+#define FTRACE(code) do { } while (0)
+#endif
+
+__device__ __forceinline__ bool ref_grid_barrier(uint32_t *ctr, uint32_t target, int *ok_lds)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > FUSED_SPIN_TICKS) { ok = 0; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *ok_lds = ok;
+    }
+    __syncthreads();
+    return *ok_lds != 0;
+}
+
+template <bool WINDOW>
+__global__ __launch_bounds__(BLK) void k_ref_fused(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
+                                                   IcpState *__restrict__ st, IcpParams prm, float thr, double *__restrict__ partials, int nblocks, uint32_t *__restrict__ bar)
+{
+    const int b = blockIdx.y, bx = blockIdx.x;
+    __shared__ IcpState S;
+    __shared__ double rec[REC_STRIDE];
+    __shared__ sf::WaveNN nn_ws[BLK / 64];
+    __shared__ int bar_ok;
+    static_assert(sizeof(IcpState) % 4 == 0, "copied word by word");
+    for (int k = threadIdx.x; k < (int)(sizeof(IcpState) / 4); k += BLK) reinterpret_cast<uint32_t *>(&S)[k] = reinterpret_cast<const uint32_t *>(st + b)[k];
+    __syncthreads();
+    uint32_t *ctr = bar + 2 * b, *fin = bar + 2 * b + 1;
+    double *slab = partials + (size_t)b * nblocks * REC_STRIDE;
+    const int i = bx * BLK + (int)threadIdx.x;
+    float x = 0.0f, y = 0.0f, z = 0.0f, tx = 0.0f, ty = 0.0f, tz = 0.0f;
+    int corr = -1;
+    if (i < n) { // X <- init * X0 (k_ref_init)
+        const size_t o = (size_t)b * n + i;
+        const float x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
+        float T[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T[k] = (float)S.T[k];
+        x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], x0), __fmul_rn(T[1], y0)), __fmul_rn(T[2], z0)), T[3]);
+        y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], x0), __fmul_rn(T[5], y0)), __fmul_rn(T[6], z0)), T[7]);
+        z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], x0), __fmul_rn(T[9], y0)), __fmul_rn(T[10], z0)), T[11]);
+        corr = 0;
+    }
+    uint32_t passed = 0; // grid barriers behind this workgroup
+    bool alive = true;   // false: a barrier timed out
+#ifdef SF_FUSED_TRACE
+    int tr_n = 0;
+#endif
+    FTRACE(0);
+    // sourceTargetCorrespondences (k_ref_nn): points without a match die for good
+    auto search = [&]() {
+        const bool live = corr >= 0;
+        const sf::NNHit hit = sf::nn_search_wave<WINDOW, true>(g, w, live, x, y, z, thr, &nn_ws[threadIdx.x >> 6]);
+        if (live) { corr = hit.j; tx = hit.px; ty = hit.py; tz = hit.pz; }
+        __syncthreads();
+        FTRACE(1);
+    };
+    // k_ref_red + the fixed-order sum of k_ref_decide: rec <- record of the live pairs (after the pending step, if asked)
+    auto record = [&](bool apply_step) {
+        double acc[NREC_P2P];
+#pragma unroll
+        for (int c = 0; c < NREC_P2P; ++c) acc[c] = 0.0;
+        if (corr >= 0) {
+            if (apply_step && S.step_pending) {
+                const float nx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(S.step[0], x), __fmul_rn(S.step[1], y)), __fmul_rn(S.step[2], z)), S.step[3]);
+                const float ny = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(S.step[4], x), __fmul_rn(S.step[5], y)), __fmul_rn(S.step[6], z)), S.step[7]);
+                const float nz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(S.step[8], x), __fmul_rn(S.step[9], y)), __fmul_rn(S.step[10], z)), S.step[11]);
+                x = nx; y = ny; z = nz;
+            }
+            const float dx = x - tx, dy = y - ty, dz = z - tz;
+            const float nrm = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz))));
+            const double sx = x, sy = y, sz = z, px = tx, py = ty, pz = tz;
+            acc[0] += 1.0;
+            acc[1] += sx; acc[2] += sy; acc[3] += sz;
+            acc[4] += px; acc[5] += py; acc[6] += pz;
+            acc[7] += sx * px; acc[8] += sx * py; acc[9] += sx * pz;
+            acc[10] += sy * px; acc[11] += sy * py; acc[12] += sy * pz;
+            acc[13] += sz * px; acc[14] += sz * py; acc[15] += sz * pz;
+            acc[16] += (double)nrm;
+        }
+        block_reduce_store<NREC_P2P>(acc, slab + (size_t)bx * REC_STRIDE);
+        FTRACE(2);
+        ++passed;
+        alive = ref_grid_barrier(ctr, passed * (uint32_t)nblocks, &bar_ok);
+        FTRACE(3);
+        if (alive) reduce_partials<NREC_P2P, BLK>(slab, nblocks, rec);
+        FTRACE(4);
+    };
+    auto decide = [&](int phase) {
+        if (threadIdx.x == 0) ref_decide(&S, rec, prm, phase);
+        __syncthreads();
+        FTRACE(5);
+    };
+    const int K = prm.num_iters;
+    if (!S.done) {
+        search();
+        record(false);
+        if (alive) decide(0);
+        for (int it = 0; alive && it < K && !S.done; ++it) {
+            decide(1);
+            if (S.done) break;
+            if (S.research) {
+                search();
+                record(false);
+                if (!alive) break;
+                decide(2);
+                if (S.done) break;
+            }
+            if (it + 1 < K) record(true);
+        }
+    }
+    __syncthreads();
+#ifdef SF_FUSED_TRACE
+    if (bx == 0 && b == 0 && threadIdx.x == 0) g_fused_trace[0] = (unsigned long long)tr_n;
+#endif
+    if (!alive) {
+        if (threadIdx.x == 0) atomicOr(&st[b].flags, SF_ICP_FLAG_BARRIER_TIMEOUT);
+        return; // the counters stay as they are: the host resets them when it sees the flag
+    }
+    if (bx == 0)
+        for (int k = threadIdx.x; k < (int)(sizeof(IcpState) / 4); k += BLK) reinterpret_cast<uint32_t *>(st + b)[k] = reinterpret_cast<const uint32_t *>(&S)[k];
+    // the workgroup that leaves last puts the counters back to zero for the next launch (everybody is past its last barrier)
+    if (threadIdx.x == 0) {
+        const uint32_t left = __hip_atomic_fetch_add(fin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == (uint32_t)nblocks - 1u) {
+            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 } // namespace
@@ -1215,6 +1388,12 @@ struct sf_icp {
     sf::DevBuf d_box;                        // sf::MinMaxDev: bounding box of the source batch (finite points), left on the device
     sf::DevBuf stage;                        // persistent upload staging of sf_icp_set_source* (AoS)
     int last_mode = 0;
+    // REF_CPP in one launch (k_ref_fused)
+    bool fused = true;       // sf_icp_set_fused
+    bool last_fused = false; // the last alignment ran as the single launch
+    sf::DevBuf bar;          // per scan: {arrival counter, departure counter} of the grid barrier
+    int fused_limit = -1;    // workgroups that are certainly resident together (-1: not asked yet)
+    int64_t fused_launches = 0;
     // graph
     bool use_graph = false;
     hipGraphExec_t graph_exec = nullptr;
@@ -1538,6 +1717,67 @@ int enqueue_align(sf_icp *icp, int mode)
     return SF_OK;
 }
 
+// The single-launch form needs every workgroup of the grid resident at once (its grid barrier waits for all of them).
+// The occupancy query can read one workgroup per CU high on this part (MI355X_MICROARCH.md, residency), so one is
+// taken off and the rest capped at 4 per CU; larger alignments take the launch list.
+int fused_capacity(sf_icp *icp)
+{
+    if (icp->fused_limit >= 0) return icp->fused_limit;
+    int per_cu_w = 0, per_cu = 0;
+    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_ref_fused<true>, BLK, 0);
+    hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ref_fused<false>, BLK, 0);
+    hipDeviceProp_t prop;
+    hipError_t e3 = hipGetDeviceProperties(&prop, icp->ctx->device);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { icp->fused_limit = 0; return 0; }
+    const int k = std::min(std::min(per_cu_w, per_cu) - 1, 4);
+    icp->fused_limit = std::max(k, 0) * prop.multiProcessorCount;
+    return icp->fused_limit;
+}
+
+bool fused_eligible(sf_icp *icp, int mode)
+{
+    return mode == SF_ICP_REF_CPP && icp->fused && !icp->profiling && !icp->shard && (int64_t)icp->nblocks * icp->batch <= (int64_t)fused_capacity(icp);
+}
+
+int launch_fused(sf_icp *icp)
+{
+    sf_map *m = icp->map;
+    hipStream_t s = icp->ctx->stream;
+    const int B = icp->batch;
+    const size_t need = sizeof(uint32_t) * 2 * (size_t)B;
+    if (icp->bar.cap < need) {
+        SF_TRY(icp->bar.reserve(need));
+        SF_HIP(hipMemsetAsync(icp->bar.p, 0, icp->bar.cap, s)); // afterwards the kernel leaves the counters at zero itself
+    }
+    const dim3 grid((unsigned)icp->nblocks, (unsigned)B);
+    const float thr = icp->prm.max_corr; // squared-vs-unsquared quirk, icp_point_to_point.cpp:70
+    IcpParams prm = icp->prm;
+    if (m->window.kind != 0)
+        hipLaunchKernelGGL(k_ref_fused<true>, grid, dim3(BLK), 0, s, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n, icp->state.as<IcpState>(), prm, thr,
+                           icp->partials.as<double>(), icp->nblocks, icp->bar.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_ref_fused<false>, grid, dim3(BLK), 0, s, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n, icp->state.as<IcpState>(), prm, thr,
+                           icp->partials.as<double>(), icp->nblocks, icp->bar.as<uint32_t>());
+    SF_HIP(hipGetLastError());
+    icp->fused_launches += 1;
+    return SF_OK;
+}
+
+// a grid barrier of the single-launch form gave up (it never should: the grid is sized to be resident): the counters are
+// put back and the alignment is reported as failed
+int check_barrier_flags(sf_icp *icp)
+{
+    if (!icp->last_fused) return SF_OK;
+    bool bad = false;
+    for (int b = 0; b < icp->batch; ++b) bad = bad || (icp->h_state[(size_t)b].flags & SF_ICP_FLAG_BARRIER_TIMEOUT);
+    if (!bad) return SF_OK;
+    hipError_t e = hipMemsetAsync(icp->bar.p, 0, icp->bar.cap, icp->ctx->stream);
+    (void)e;
+    icp->fused_limit = 0; // no second attempt on this object
+    sf::set_error("REF_CPP single-launch alignment: a grid barrier timed out (results invalid); the launch list is used from now on");
+    return SF_ERR_HIP;
+}
+
 int check_ready(sf_icp *icp, int mode)
 {
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
@@ -1607,7 +1847,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
     if (icp->inits_ev) { e = hipEventDestroy(icp->inits_ev); (void)e; }
     if (icp->h_inits) { e = hipHostFree(icp->h_inits); (void)e; }
-    icp->X0.release(); icp->X0r.release(); icp->qcache.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->state.release(); icp->d_inits.release();
+    icp->X0.release(); icp->X0r.release(); icp->qcache.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->bar.release(); icp->state.release(); icp->d_inits.release();
     icp->n_dev.release(); icp->nn_stats.release(); icp->d_box.release(); icp->stage.release(); icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
@@ -1726,6 +1966,25 @@ extern "C" int sf_icp_graph_counts(sf_icp *icp, int64_t *captures, int64_t *laun
     return SF_OK;
 }
 
+// REF_CPP alignments whose workgroups are all resident at once run as ONE launch (k_ref_fused) unless this is switched
+// off; launches (optional) <- how many alignments have taken that form
+extern "C" int sf_icp_set_fused(sf_icp *icp, int on)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    icp->fused = on != 0;
+    return SF_OK;
+}
+
+#ifdef SF_FUSED_TRACE
+extern "C" int sf_icp_fused_trace(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_trace), sizeof(unsigned long long) * 512) == hipSuccess ? SF_OK : SF_ERR_HIP; }
+#endif
+extern "C" int sf_icp_fused_count(sf_icp *icp, int64_t *launches)
+{
+    SF_CHECK(icp && launches, SF_ERR_INVALID, "bad arguments");
+    *launches = icp->fused_launches;
+    return SF_OK;
+}
+
 extern "C" int sf_icp_use_graph(sf_icp *icp, int on)
 {
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
@@ -1741,6 +2000,11 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     hipStream_t s = icp->ctx->stream;
     icp->last_mode = mode;
     SF_TRY(launch_state_init(icp));
+    icp->last_fused = fused_eligible(icp, mode);
+    if (icp->last_fused) { // REF_CPP, everything resident at once: the whole alignment is one launch (window and count by value)
+        SF_TRY(order_queries(icp, mode));
+        return launch_fused(icp);
+    }
     if (mode == SF_ICP_REF_CPP && icp->map->window.kind != 0) { // the map crop as it stands now, for the kernels that read it from the device
         SF_TRY(icp->map->d_window.reserve(sizeof(SfWindow)));
         hipLaunchKernelGGL(k_set_window, dim3(1), dim3(1), 0, s, icp->map->d_window.as<SfWindow>(), icp->map->window);
@@ -1785,6 +2049,7 @@ extern "C" int sf_icp_fetch_results(sf_icp *icp, sf_icp_result *out)
     SF_HIP(hipMemcpyAsync(icp->h_state.data(), icp->state.p, sizeof(IcpState) * (size_t)icp->batch, hipMemcpyDeviceToHost, s));
     SF_HIP(hipStreamSynchronize(s));
     if (icp->profiling) prof_collect(icp);
+    SF_TRY(check_barrier_flags(icp));
     for (int b = 0; b < icp->batch; ++b) fill_result(icp, icp->last_mode, icp->h_state[(size_t)b], &icp->inits[(size_t)b * 16], out + b);
     return SF_OK;
 }

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_map_nn_t(SfGrid g, SfWindow w, const fl
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     const float qx = valid ? q[3 * i] : 0.0f, qy = valid ? q[3 * i + 1] : 0.0f, qz = valid ? q[3 * i + 2] : 0.0f;
-    const sf::NNHit hit = sf::nn_search_wave<WINDOW>(g, w, valid, qx, qy, qz, thr, &ws[threadIdx.x >> 6]);
+    const sf::NNHit hit = sf::nn_search_wave<WINDOW, true>(g, w, valid, qx, qy, qz, thr, &ws[threadIdx.x >> 6]);
     if (!valid) return;
     idx[i] = hit.j >= 0 ? (int32_t)__float_as_uint(g.pts[hit.j].w) : -1;
     d2[i] = hit.j >= 0 ? hit.d2 : INFINITY;

@@ -397,7 +397,8 @@ __device__ __forceinline__ float row_gap2(const QueryGeo &G, int k)
 // CURRENT squared distance seed.d2 (l2_simple of the query and the point).  The search then starts from that bound
 // instead of the acceptance threshold: the same exact result (the seed is a candidate like any other, met again when
 // its range is scanned), most neighbour ranges pruned before they are visited.
-template <bool WINDOW>
+// COOP: how the rare queries that need more than ring 1 go on (see the end of the function)
+template <bool WINDOW, bool COOP = false>
 __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow &w, bool valid, float qx, float qy, float qz, float thr, WaveNN *ws, NNHit seed = NNHit{0.0f, -1, 0.0f, 0.0f, 0.0f, 0.0f})
 {
     const int lane = (int)__lane_id();
@@ -506,6 +507,7 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    bool more = false; // ring 1 did not settle this query
     if (valid) {
         const unsigned long long m = ws->best[lane];
         const int j = (int)(uint32_t)m;
@@ -516,7 +518,7 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
             hit.j = j;
             hit.px = p.x; hit.py = p.y; hit.pz = p.z;
         }
-        // exactness of ring 1 (same test as nn_rings); otherwise continue with ring 2 per lane (rare)
+        // exactness of ring 1 (same test as nn_rings); otherwise on to ring 2
         const float gx = (qx - g.org[0]) * g.inv_h, gy = (qy - g.org[1]) * g.inv_h, gz = (qz - g.org[2]) * g.inv_h;
         const int cx = (int)fminf(fmaxf(floorf(gx), 0.0f), (float)(nx - 1));
         const int cy = (int)fminf(fmaxf(floorf(gy), 0.0f), (float)(ny - 1));
@@ -532,11 +534,102 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
         const float mm = safe_gap(mface, g.gap_eps) * 0.999f;
         if (mface < 3.0e38f) {
             hit.lb2 = fminf(hit.lb2, mm * mm); // nothing outside the 27 cells is closer than their boundary
-            if (!(hit.d2 <= mm * mm)) {
-                nn_rings<WINDOW>(g, w, qx, qy, qz, 2, hit);
-                hit.lb2 = 0.0f; // no bound kept for the per-lane rings
+            more = !(hit.d2 <= mm * mm);
+        }
+        if (!COOP && more) { // lane by lane (the dense batch kernels: rare there, and the cooperative form below costs k_nn_red 8 VGPRs = one wave per SIMD)
+            nn_rings<WINDOW>(g, w, qx, qy, qz, 2, hit);
+            hit.lb2 = 0.0f; // no bound kept for the per-lane rings
+        }
+    }
+    if (!COOP) return hit;
+    // COOP: queries whose best is still farther than the boundary of their 27 cells (scan points with no map point nearby:
+    // new ground, moving objects, the rim of the map crop) go on ring by ring TOGETHER.  Lane by lane that is a serial walk
+    // of (2R+1)^2 rows by a handful of lanes while the rest of the wave idles -- measured on the per-scan path: it made
+    // every index cell below the acceptance radius slower than a 0.72 m cell (alignment 409 us at 0.72 m; 557 / 498 us at
+    // 0.5 / 0.36 m lane by lane, 349 / 355 us with this).  Here the (query, row) pairs of ring R are dealt out over all 64
+    // lanes like the ring-1 tasks: rows outside the previous block are scanned whole, rows inside it only in their two new
+    // end cells, each pruned by its gap against the owner's best as it stands.  Same result as nn_rings: the lexicographic
+    // minimum of (d2, j) over everything visited, and only ranges that cannot hold a better candidate are skipped.
+    unsigned long long unres = __ballot(more);
+    const int rcap = max(nx, max(ny, nz));
+    for (int R = 2; unres != 0ull && R <= rcap; ++R) {
+        {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(unres >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)unres, 0u));
+            if (more) {
+                ws->task[rank] = (uint16_t)lane;
+                ws->best[lane] = pack_hit(hit.d2, hit.j);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int side = 2 * R + 1, nrows = side * side, total = __popcll(unres) * nrows;
+        const float h = g.h, ge = g.gap_eps;
+        for (int idx = lane; idx < total; idx += 64) {
+            const int u = idx / nrows, r = idx - u * nrows;
+            const int owner = (int)ws->task[u];
+            const int dyi = r / side - R, dzi = r - (r / side) * side - R;
+            const float4 Q = ws->q[owner];
+            const float gx = (Q.x - g.org[0]) * g.inv_h, gy = (Q.y - g.org[1]) * g.inv_h, gz = (Q.z - g.org[2]) * g.inv_h;
+            const int cx = (int)fminf(fmaxf(floorf(gx), 0.0f), (float)(nx - 1));
+            const int cy = (int)fminf(fmaxf(floorf(gy), 0.0f), (float)(ny - 1));
+            const int cz = (int)fminf(fmaxf(floorf(gz), 0.0f), (float)(nz - 1));
+            const int y = cy + dyi, z = cz + dzi;
+            if ((unsigned)y >= (unsigned)ny || (unsigned)z >= (unsigned)nz) continue;
+            const float ry = safe_gap(cell_gap(gy, y, cy) * h, ge), rz = safe_gap(cell_gap(gz, z, cz) * h, ge);
+            const float g2 = ry * ry + rz * rz;
+            const unsigned long long start = __atomic_load_n(&ws->best[owner], __ATOMIC_RELAXED);
+            const float cur = __uint_as_float((uint32_t)(start >> 32));
+            if (g2 * 0.998f >= cur) continue;
+            NNHit t;
+            t.d2 = cur;
+            t.j = (int)(uint32_t)start;
+            t.px = t.py = t.pz = 0.0f;
+            t.lb2 = 0.0f;
+            const size_t row = ((size_t)z * ny + y) * nx;
+            const bool inner = abs(dyi) < R && abs(dzi) < R; // scanned up to x +- (R - 1) by the rings before
+            if (!inner) {
+                const int x0 = max(cx - R, 0), x1 = min(cx + R, nx - 1);
+                scan_range<WINDOW>(g, w, g.cell_start[row + x0], g.cell_start[row + x1 + 1], Q.x, Q.y, Q.z, t);
+            } else {
+                if (cx - R >= 0) {
+                    const float gl = safe_gap((gx - (float)(cx - R + 1)) * h, ge);
+                    if ((g2 + gl * gl) * 0.998f < t.d2) scan_range<WINDOW>(g, w, g.cell_start[row + cx - R], g.cell_start[row + cx - R + 1], Q.x, Q.y, Q.z, t);
+                }
+                if (cx + R <= nx - 1) {
+                    const float gr = safe_gap(((float)(cx + R) - gx) * h, ge);
+                    if ((g2 + gr * gr) * 0.998f < t.d2) scan_range<WINDOW>(g, w, g.cell_start[row + cx + R], g.cell_start[row + cx + R + 1], Q.x, Q.y, Q.z, t);
+                }
+            }
+            const unsigned long long mine = pack_hit(t.d2, t.j);
+            if (mine != start) atomicMin(&ws->best[owner], mine);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (more) {
+            const unsigned long long m = ws->best[lane];
+            const int j = (int)(uint32_t)m;
+            if (j != hit.j) {
+                const float4 p = g.pts[j];
+                hit.d2 = __uint_as_float((uint32_t)(m >> 32));
+                hit.j = j;
+                hit.px = p.x; hit.py = p.y; hit.pz = p.z;
+            }
+            hit.lb2 = 0.0f; // no runner-up bound is kept beyond ring 1
+            const float gx = (qx - g.org[0]) * g.inv_h, gy = (qy - g.org[1]) * g.inv_h, gz = (qz - g.org[2]) * g.inv_h;
+            const int cx = (int)fminf(fmaxf(floorf(gx), 0.0f), (float)(nx - 1));
+            const int cy = (int)fminf(fmaxf(floorf(gy), 0.0f), (float)(ny - 1));
+            const int cz = (int)fminf(fmaxf(floorf(gz), 0.0f), (float)(nz - 1));
+            float mface = 3.0e38f; // the nearest face of the block of radius R that still has grid cells behind it
+            if (cx - R > 0) mface = fminf(mface, (gx - (float)(cx - R)) * h);
+            if (cx + R < nx - 1) mface = fminf(mface, ((float)(cx + R + 1) - gx) * h);
+            if (cy - R > 0) mface = fminf(mface, (gy - (float)(cy - R)) * h);
+            if (cy + R < ny - 1) mface = fminf(mface, ((float)(cy + R + 1) - gy) * h);
+            if (cz - R > 0) mface = fminf(mface, (gz - (float)(cz - R)) * h);
+            if (cz + R < nz - 1) mface = fminf(mface, ((float)(cz + R + 1) - gz) * h);
+            const float mm = safe_gap(mface, ge) * 0.999f;
+            more = mface < 3.0e38f && !(hit.d2 <= mm * mm);
+        }
+        unres = __ballot(more);
     }
     return hit;
 }

@@ -22,7 +22,7 @@ class LocalizationFlow:
     # grid cell of the whole-map index: the reference's "d2 < 0.5" rule (icp_point_to_point.cpp:70) is a 0.707 m search
     # radius on a stride-3 map (0.3 m point spacing); a cell of that size keeps every search inside the 27-cell block
     # (automatic sizing, 1.5 points per cell, sends each query without a neighbour through a second ring, lane by lane)
-    index_cell_ = 0.72
+    index_cell_ = 0.5
     pcl_crop_order_ = False            # True: the scan crop keeps PCL's ascending-distance output order (point_cloud_processing.hpp:40-52)
 
     def __init__(self, ctx, map_points, map_T_global, altitude_table=None, map_is_downsampled=True):

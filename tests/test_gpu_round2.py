@@ -182,6 +182,7 @@ def test_single_scan_ref_cpp_graph_survives_changing_counts_and_windows(api, ctx
     p = api.Icp(ctx, 0.5, 10, 0.001, 1e-5)
     for icp in (g, p):
         icp.set_target(mp)
+        icp.set_fused(False)                                     # the launch list is what a graph captures (the single-launch form: next test)
     g.use_graph(True)
     rng = np.random.default_rng(8)
     for k, n in enumerate((9000, 8700, 9500, 8200, 9900)):
@@ -206,6 +207,60 @@ def test_single_scan_ref_cpp_graph_survives_changing_counts_and_windows(api, ctx
     g.set_source(synth.make_scan(m, 3000, scan_id=99)[0])      # another capacity class: one more capture
     g.align("ref_cpp")
     assert g.graph_counts() == (2, 6)
+
+
+def test_ref_cpp_single_launch_equals_launch_list(api, ctx, orc, synth, small_world):
+    """REF_CPP with every workgroup resident at once runs as ONE launch (k_ref_fused: grid barriers instead of kernel
+    boundaries, the controller evaluated by every workgroup): bit-identical to the launch list in every parameter case of
+    the parity test (early accept, iteration cap, lazy re-search, strong fallback), with a sphere / box window, for a
+    batch of scans of which one dies at once, and for a stream of scans through one object."""
+    m = small_world["map"]
+    mp = api.Map(ctx, api.Cloud(ctx, m), 0.25)
+    cases = [dict(max_corr=0.5, iters=10, accept=0.05, eps=1e-5), dict(max_corr=0.5, iters=10, accept=0.001, eps=1e-5),
+             dict(max_corr=0.5, iters=15, accept=0.001, eps=5e-3), dict(max_corr=5.0, iters=80, accept=0.4, eps=1e-2), dict(max_corr=0.5, iters=0, accept=0.001, eps=1e-5)]
+    keys = ("iterations", "converged", "n_corr", "n_research", "flags", "error")
+    scans = np.stack([synth.make_scan(m, 7000, scan_id=50 + k)[0] for k in range(3)])
+    scans[2] += np.float32(400.0)                                   # nothing within reach: < 10 correspondences, initial T back
+    inits = np.stack([synth.make_T((0.02 * k, -0.01, 0.0), (0, 0.02, 0.1 * k)) for k in range(3)])
+    for case in cases:
+        for window in (None, "sphere", "box"):
+            if window == "sphere":
+                mp.window_sphere(np.array([0.2, -0.1, 0.0], np.float32), 4.5)
+            elif window == "box":
+                mp.window_obb(np.array([0.1, 0.2, 0.0]), synth.make_T((0, 0, 0), (0, 0, 20.0))[:3, :3], np.array([4.0, 3.5, 2.0]))
+            else:
+                mp.window_none()
+            out = []
+            for fused in (True, False):
+                icp = api.Icp(ctx, case["max_corr"], case["iters"], case["accept"], case["eps"])
+                icp.set_fused(fused)
+                icp.set_target(mp)
+                icp.set_source_batch(scans)
+                icp.set_initial_batch(inits)
+                r = icp.align_batch("ref_cpp")
+                assert icp.fused_count() == (1 if fused else 0)
+                icp.set_source(scans[1][:4321])                    # one scan, a count that is no multiple of anything
+                icp.set_initial_transformation(inits[1].astype(np.float32))
+                r.append(icp.align("ref_cpp"))
+                assert icp.fused_count() == (2 if fused else 0)
+                out.append(r)
+            for a, b in zip(*out):
+                assert np.array_equal(a["T64"], b["T64"]) and all(a[k] == b[k] for k in keys), (case, window)
+            assert out[0][2]["flags"] & api.SF_ICP_FLAG_FEW_CORR and out[0][2]["iterations"] == 0
+    mp.window_none()
+    icp = api.Icp(ctx, 0.5, 10, 0.001, 1e-5)                        # a stream through one object: the barrier counters return to zero
+    icp.set_target(mp)
+    for k in range(6):
+        scan = synth.make_scan(m, 5000 + 700 * k, scan_id=70 + k)[0]
+        init = synth.make_T((0.01 * k, 0.0, 0.0), (0, 0, 0.05 * k)).astype(np.float32)
+        icp.set_source(scan)
+        icp.set_initial_transformation(init)
+        r = icp.align("ref_cpp")
+        o = orc.icp_ref_cpp(scan, m, init, 0.5, 10, 0.001, 1e-5, precise=True)
+        assert r["iterations"] == o["iterations"] and r["n_corr"] == o["n_corr"]
+        dt, dr = synth.pose_error(r["T64"], o["T"])
+        assert dt < 1e-4 and dr < 1e-5
+    assert icp.fused_count() == 6
 
 
 def test_gpu_against_golden_extensions(api, ctx):
