@@ -395,6 +395,66 @@ float sf_sfilter_pose_zscore(const sf_sfilter *f, const float prev[16], const fl
 void sf_sfilter_apply_gaussian_filter(const sf_sfilter *f, const float prev[16],
                                       const float cur[16], float out[16]);
 
+/* ------------------------------------------------------------------ the node's per-scan callback as one call
+ * LocalizationNode::localizationCallback and its helpers -- localization/src/localization_node.cpp:263-344 (callback),
+ * :62-77 (compass), :112-128 (GPS pose), :181-261 (coarse alignment), constructor constants :19-43 -- over the entry
+ * points above: same order, same constants, same state, everything device-side on the context's stream.  The ROS 2 shell
+ * (subscriptions, synchroniser, publishers) stays with the caller. */
+typedef struct sf_node sf_node;
+typedef struct {
+    float ref_frame_distance; /* 3 m: re-crop distance, localization_node.h:142                                     */
+    float cloud_crop_radius;  /* 10 m: scan and map crop radius, localization_node.h:145                            */
+    float index_cell;         /* grid cell of the whole-map index (0.5 m; 0 = automatic)                              */
+    int32_t pcl_crop_order;   /* 1: the scan crop keeps PCL's ascending-distance order (point_cloud_processing.hpp:40-52) */
+    int32_t icp_mode;         /* SF_ICP_REF_CPP (the node's ICPPointToPoint)                                          */
+    int32_t map_is_downsampled; /* 0: apply getMapCloud's 0.1 m voxel grid (:19) before the stride-3 subsample (:20) */
+} sf_node_params;
+typedef struct { /* the sensor_msgs/NavSatFix fields the node reads */
+    double latitude, longitude, altitude;
+    double position_covariance[9];
+} sf_gps_fix;
+typedef struct { /* the nav_msgs/Odometry fields the node reads */
+    double q_wxyz[4];
+    double t[3];
+    double covariance[36];
+} sf_odom;
+#define SF_NODE_OK 0              /* map_T_sensor is the new pose                                           */
+#define SF_NODE_GATED_ALTITUDE 1  /* negative GPS altitude: message dropped (:269-276)                       */
+#define SF_NODE_FIRST_MESSAGE 2   /* first message: pose initialised from GPS + compass, no alignment (:278-283) */
+#define SF_NODE_COARSE_FAILED 3   /* the start-up lock was not found on this scan (:307-315)                 */
+typedef struct {
+    int32_t status;          /* SF_NODE_*                                                                     */
+    int32_t recropped;       /* the map window moved on this scan (:299-305)                                  */
+    int32_t coarse_ran;      /* 0 no, 1 brute force only, 2 brute force + the "strong" ICP                    */
+    int32_t pad_;
+    int64_t n_scan;          /* scan points after the stride-2 subsample and the radius crop                  */
+    float map_T_sensor[16];  /* the node's pose after this message                                            */
+    float prior[16];         /* the filtered prior handed to the ICP (:318-332)                               */
+    float odom_pose[16], gps_pose[16];
+    float odometry_gain, gps_compass_gain;
+    sf_icp_result icp;       /* the fine alignment                                                            */
+    sf_icp_result coarse_icp; /* the "strong" ICP of the coarse phase when coarse_ran == 2                    */
+} sf_node_output;
+void sf_node_default_params(sf_node_params *p);
+/* map_xyz: the map cloud (getMapCloud's output when map_is_downsampled); altitude table rows = (lat, lon, alt) */
+int sf_node_create(sf_ctx *ctx, const float *map_xyz, int64_t n_map, const double map_T_global[16], const double *altitude_table_lat_lon_alt, int rows,
+                   const sf_node_params *params /* or NULL */, sf_node **out);
+void sf_node_destroy(sf_node *n);
+int sf_node_compass(sf_node *n, double compass_deg); /* compassCallback :62-77 */
+int sf_node_callback_xyz(sf_node *n, const float *xyz, int64_t n_points, const sf_gps_fix *gps, const sf_odom *odom, sf_node_output *out);
+int sf_node_callback_pointcloud2(sf_node *n, const void *data, int64_t data_bytes, int64_t width, int64_t height, int point_step, int64_t row_step, int off_x, int off_y,
+                                 int off_z, int datatype, int is_bigendian, const sf_gps_fix *gps, const sf_odom *odom, sf_node_output *out);
+#define SF_NODE_POSE_MAP_T_SENSOR 0
+#define SF_NODE_POSE_MAP_T_REF 1
+#define SF_NODE_POSE_ODOM_PREVIOUS 2
+int sf_node_set_pose(sf_node *n, int which, const float T[16]); /* callers that already hold a lock */
+int sf_node_get_pose(sf_node *n, int which, float T[16]);
+int sf_node_set_coarse_alignment_complete(sf_node *n, int complete);
+int sf_node_coarse_alignment_complete(sf_node *n);
+sf_icp *sf_node_icp(sf_node *n); /* the node's icp_ (parameters, counters) */
+struct sf_bf;
+struct sf_bf *sf_node_bf(sf_node *n); /* the node's brute_force_alignment_ (pose grid, threshold) */
+
 /* f-4 (EXTENSION, no reference counterpart): error-state EKF pose prior with IMU pre-integration.
  * The reference has no EKF and never reads the IMU (SURVEY.md "Read this first"); its prior is the
  * blend + StochasticFilter above.  Nominal state: position, velocity (map frame), attitude R (map <- sensor),

@@ -45,7 +45,7 @@ _live = weakref.WeakSet()   # every wrapper object, closed in dependency order a
 
 
 def _close_all():
-    for kind in ("Comm", "Icp", "BruteForceAlignment", "Map", "Cloud", "Context"):
+    for kind in ("Node", "Comm", "Icp", "BruteForceAlignment", "Map", "Cloud", "Context"):
         for obj in [o for o in list(_live) if type(o).__name__ == kind]:
             try:
                 obj.close()
@@ -81,6 +81,8 @@ def load_library():
     lib.sf_cloud_device_ptr.restype = C.c_void_p
     lib.sf_icp_exchange_ptr.restype = C.c_void_p
     lib.sf_sfilter_create.restype = C.c_void_p
+    lib.sf_node_icp.restype = C.c_void_p
+    lib.sf_node_bf.restype = C.c_void_p
     lib.sf_fusion_compass_to_yaw.restype = C.c_float
     lib.sf_fusion_closest_altitude.restype = C.c_float
     lib.sf_sfilter_pose_zscore.restype = C.c_float
@@ -103,6 +105,20 @@ def _f64(a):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def _pc2_layout(msg):
+    """(buffer, width, height, point_step, row_step, (off_x, off_y, off_z), datatype, is_bigendian) of a PointCloud2-like message"""
+    offs, types = {"x": 0, "y": 4, "z": 8}, {"x": 7, "y": 7, "z": 7}
+    for f in getattr(msg, "fields", []) or []:
+        if f.name in offs:
+            offs[f.name] = int(f.offset)
+            types[f.name] = int(getattr(f, "datatype", 7))
+    if len(set(types.values())) != 1:
+        raise SlamFusionError("PointCloud2 x/y/z fields have different datatypes: %r" % (types,))
+    buf = np.frombuffer(msg.data, dtype=np.uint8)
+    return (buf, int(msg.width), int(msg.height), int(msg.point_step), int(getattr(msg, "row_step", 0) or 0), (offs["x"], offs["y"], offs["z"]), types["x"],
+            int(bool(getattr(msg, "is_bigendian", False))))
 
 
 class Context:
@@ -166,18 +182,9 @@ class Cloud:
         """PointCloud2-like message (width, height, point_step, row_step, is_bigendian, fields or x/y/z float32 at
         0/4/8, data).  The buffer length, the x/y/z datatype (FLOAT32 = 7 or FLOAT64 = 8, all three alike) and the
         endianness are checked here and again behind the C ABI."""
-        offs, types = {"x": 0, "y": 4, "z": 8}, {"x": 7, "y": 7, "z": 7}
-        for f in getattr(msg, "fields", []) or []:
-            if f.name in offs:
-                offs[f.name] = int(f.offset)
-                types[f.name] = int(getattr(f, "datatype", 7))
-        if len(set(types.values())) != 1:
-            raise SlamFusionError("PointCloud2 x/y/z fields have different datatypes: %r" % (types,))
-        buf = np.frombuffer(msg.data, dtype=np.uint8)
-        _check(self.lib.sf_cloud_from_pointcloud2_msg(self.h, _p(buf), C.c_int64(buf.size), C.c_int64(int(msg.width)), C.c_int64(int(msg.height)),
-                                                      C.c_int(int(msg.point_step)), C.c_int64(int(getattr(msg, "row_step", 0) or 0)),
-                                                      C.c_int(offs["x"]), C.c_int(offs["y"]), C.c_int(offs["z"]), C.c_int(types["x"]),
-                                                      C.c_int(int(bool(getattr(msg, "is_bigendian", False))))))
+        buf, width, height, point_step, row_step, offs, dtype, big = _pc2_layout(msg)
+        _check(self.lib.sf_cloud_from_pointcloud2_msg(self.h, _p(buf), C.c_int64(buf.size), C.c_int64(width), C.c_int64(height), C.c_int(point_step), C.c_int64(row_step),
+                                                      C.c_int(offs[0]), C.c_int(offs[1]), C.c_int(offs[2]), C.c_int(dtype), C.c_int(big)))
         return self
 
     def load_pcd(self, path):
@@ -720,6 +727,134 @@ class BruteForceAlignment:
     def close(self):
         if self.h:
             self.lib.sf_bf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NodeParams(C.Structure):
+    """sf_node_params"""
+    _fields_ = [("ref_frame_distance", C.c_float), ("cloud_crop_radius", C.c_float), ("index_cell", C.c_float), ("pcl_crop_order", C.c_int32),
+                ("icp_mode", C.c_int32), ("map_is_downsampled", C.c_int32)]
+
+
+class GpsFix(C.Structure):
+    """sf_gps_fix"""
+    _fields_ = [("latitude", C.c_double), ("longitude", C.c_double), ("altitude", C.c_double), ("position_covariance", C.c_double * 9)]
+
+
+class Odom(C.Structure):
+    """sf_odom"""
+    _fields_ = [("q_wxyz", C.c_double * 4), ("t", C.c_double * 3), ("covariance", C.c_double * 36)]
+
+
+class NodeOutput(C.Structure):
+    """sf_node_output"""
+    _fields_ = [("status", C.c_int32), ("recropped", C.c_int32), ("coarse_ran", C.c_int32), ("pad_", C.c_int32), ("n_scan", C.c_int64),
+                ("map_T_sensor", C.c_float * 16), ("prior", C.c_float * 16), ("odom_pose", C.c_float * 16), ("gps_pose", C.c_float * 16),
+                ("odometry_gain", C.c_float), ("gps_compass_gain", C.c_float), ("icp", IcpResult), ("coarse_icp", IcpResult)]
+
+
+SF_NODE_OK, SF_NODE_GATED_ALTITUDE, SF_NODE_FIRST_MESSAGE, SF_NODE_COARSE_FAILED = 0, 1, 2, 3
+SF_NODE_POSE_MAP_T_SENSOR, SF_NODE_POSE_MAP_T_REF, SF_NODE_POSE_ODOM_PREVIOUS = 0, 1, 2
+
+
+class _BorrowedIcp(Icp):
+    """The icp_ of a Node: same methods, the handle belongs to the node."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.h = C.c_void_p(handle)
+        self._map = None
+        self.batch = 1
+
+    def close(self):
+        self.h = C.c_void_p()
+
+
+class _BorrowedBf(BruteForceAlignment):
+    """The brute_force_alignment_ of a Node."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.h = C.c_void_p(handle)
+        self._map = None
+
+    def close(self):
+        self.h = C.c_void_p()
+
+
+class Node:
+    """sf_node: LocalizationNode's per-scan callback (localization_node.cpp:263-344) as one library call."""
+
+    def __init__(self, ctx, map_points, map_T_global, altitude_table=None, **params):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.h = C.c_void_p()
+        prm = NodeParams()
+        self.lib.sf_node_default_params(C.byref(prm))
+        for k, v in params.items():
+            if k == "icp_mode":
+                v = MODES[v] if isinstance(v, str) else v
+            setattr(prm, k, type(getattr(prm, k))(v))
+        self.params = prm
+        xyz = _f32(map_points).reshape(-1, 3)
+        M = _f64(map_T_global).reshape(16)
+        tab = _f64(np.zeros((0, 3)) if altitude_table is None else altitude_table).reshape(-1, 3)
+        _check(self.lib.sf_node_create(ctx.h, _p(xyz), C.c_int64(len(xyz)), _p(M), _p(tab), C.c_int(len(tab)), C.byref(prm), C.byref(self.h)))
+        self.icp = _BorrowedIcp(ctx, self.lib.sf_node_icp(self.h))
+        self.bf = _BorrowedBf(ctx, self.lib.sf_node_bf(self.h))
+        self._gps, self._odom, self._out = GpsFix(), Odom(), NodeOutput()
+        _live.add(self)
+
+    def compass(self, compass_deg):
+        _check(self.lib.sf_node_compass(self.h, C.c_double(compass_deg)))
+
+    def _messages(self, gps, odom):
+        g, o = self._gps, self._odom
+        g.latitude, g.longitude, g.altitude = gps["latitude"], gps["longitude"], gps["altitude"]
+        g.position_covariance[:] = gps["position_covariance"]
+        o.q_wxyz[:] = odom["q_wxyz"]
+        o.t[:] = odom["t"]
+        o.covariance[:] = odom["covariance"]
+        return g, o
+
+    def callback(self, scan, gps, odom):
+        """scan: float32 [n, 3] or a PointCloud2-like message (data, width, height, point_step, row_step, offsets);
+        returns the sf_node_output structure (valid until the next call)."""
+        g, o = self._messages(gps, odom)
+        if hasattr(scan, "point_step"):
+            buf, width, height, point_step, row_step, offs, dtype, big = _pc2_layout(scan)
+            _check(self.lib.sf_node_callback_pointcloud2(self.h, _p(buf), C.c_int64(buf.size), C.c_int64(width), C.c_int64(height), C.c_int(point_step), C.c_int64(row_step),
+                                                         C.c_int(offs[0]), C.c_int(offs[1]), C.c_int(offs[2]), C.c_int(dtype), C.c_int(big), C.byref(g), C.byref(o), C.byref(self._out)))
+        else:
+            xyz = _f32(scan).reshape(-1, 3)
+            _check(self.lib.sf_node_callback_xyz(self.h, _p(xyz), C.c_int64(len(xyz)), C.byref(g), C.byref(o), C.byref(self._out)))
+        return self._out
+
+    def get_pose(self, which=SF_NODE_POSE_MAP_T_SENSOR):
+        T = np.empty(16, np.float32)
+        _check(self.lib.sf_node_get_pose(self.h, C.c_int(which), _p(T)))
+        return T.reshape(4, 4)
+
+    def set_pose(self, which, T):
+        T = _f32(T).reshape(16)
+        _check(self.lib.sf_node_set_pose(self.h, C.c_int(which), _p(T)))
+
+    def coarse_alignment_complete(self):
+        return bool(self.lib.sf_node_coarse_alignment_complete(self.h))
+
+    def set_coarse_alignment_complete(self, v=True):
+        _check(self.lib.sf_node_set_coarse_alignment_complete(self.h, C.c_int(int(v))))
+
+    def close(self):
+        if self.h:
+            self.icp.close()
+            self.bf.close()
+            self.lib.sf_node_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

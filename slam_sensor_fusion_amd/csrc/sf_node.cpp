@@ -1,0 +1,311 @@
+// sf_node.cpp — the C++ node's per-scan orchestration as ONE call over the library's own entry points.
+//
+// Replaces the body of LocalizationNode::localizationCallback and its helpers
+// (localization/src/localization_node.cpp:263-344 callback, :62-77 compass, :112-128 GPS pose, :181-261 coarse
+// alignment; constructor constants :19-43): same order, same constants, same state variables, minus the ROS 2 shell
+// (rclcpp, message_filters, publishers: out of scope).  A maintainer keeps the node class and its
+// subscriptions and calls sf_node_callback_* from localizationCallback; the Python mirror of the same orchestration
+// (slam_sensor_fusion_amd/localization_flow.py) produces bit-identical poses (tests/test_gpu_node.py) and pays ~0.15 ms
+// per scan in interpreter overhead that this form does not.
+//
+// Host work (a14-a18: odometry prediction, GPS/compass pose, gains, blend, StochasticFilter) runs in sf_fusion.cpp;
+// device work is upload -> stride-2 subsample -> 10 m radius crop -> (window change every 3 m) -> ICP, all on the
+// context's stream.  The reference re-crops the map and rebuilds a FLANN tree every 3 m of travel (:299-305); here that
+// is a new window on the resident whole-map index.
+#include "sf_common.hpp"
+
+#include <cmath>
+
+struct sf_node {
+    sf_ctx *ctx = nullptr;
+    sf_node_params prm{};
+    sf_cloud *map_cloud = nullptr;   // map_cloud_ (:19-20: voxel 0.1, stride 3)
+    sf_map *map_index = nullptr;     // whole-map grid index; the 10 m crop is its window
+    sf_icp *icp = nullptr;           // icp_ (:24-28)
+    sf_sfilter *filter = nullptr;    // coarse_pose_filter_ (:32-34)
+    sf_bf *bf = nullptr;             // brute_force_alignment_ (:38-43)
+    sf_cloud *scan = nullptr;        // one device cloud for every scan: its buffers persist
+    sf_cloud *ref_cropped = nullptr; // ref_cropped_map_cloud_, materialised only for the coarse phase
+    sf_cloud *map_tmp = nullptr, *scan_tmp = nullptr;
+    sf_map *coarse_map = nullptr;
+    bool have_ref_cropped = false;
+    double map_T_global[16];
+    std::vector<double> altitude_table; // rows of (lat, lon, alt)
+    float map_T_sensor[16], odom_T_sensor_previous[16], map_T_ref[16];
+    float current_compass_yaw = 0.0f;
+    bool first_time = true, have_window = false, coarse_alignment_complete = false;
+};
+
+namespace {
+
+void eye4(float *T)
+{
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+}
+
+// computeGpsCoarsePoseInMapFrame, localization_node.cpp:112-128
+void gps_coarse_pose(const sf_node *n, double lat, double lon, float out[16])
+{
+    const float alt = sf_fusion_closest_altitude(n->altitude_table.data(), (int)(n->altitude_table.size() / 3), lat, lon);
+    sf_fusion_gps_pose(n->map_T_global, n->current_compass_yaw, lat, lon, alt, out);
+}
+
+// performCoarseAlignment, localization_node.cpp:200-261: brute force over the pose grid, else the "strong" ICP
+int coarse_alignment(sf_node *n, sf_node_output *out, bool *locked)
+{
+    *locked = false;
+    if (sf_bf_first_alignment_completed(n->bf)) { *locked = true; return SF_OK; }
+    if (!n->have_ref_cropped) { // cropPointCloudThroughRadius output, PCL order (:302)
+        if (!n->ref_cropped) SF_TRY(sf_cloud_create(n->ctx, &n->ref_cropped));
+        SF_TRY(sf_cloud_copy(n->ref_cropped, n->map_cloud));
+        const float c[3] = {n->map_T_ref[3], n->map_T_ref[7], n->map_T_ref[11]};
+        SF_TRY(sf_cloud_crop_radius(n->ref_cropped, c, (double)n->prm.cloud_crop_radius, 1));
+        n->have_ref_cropped = true;
+    }
+    if (!n->map_tmp) SF_TRY(sf_cloud_create(n->ctx, &n->map_tmp));
+    if (!n->scan_tmp) SF_TRY(sf_cloud_create(n->ctx, &n->scan_tmp));
+    SF_TRY(sf_cloud_copy(n->map_tmp, n->ref_cropped));
+    SF_TRY(sf_cloud_copy(n->scan_tmp, n->scan));
+    SF_TRY(sf_cloud_subsample(n->map_tmp, 15));  // :211
+    SF_TRY(sf_cloud_remove_floor(n->map_tmp));   // :212
+    SF_TRY(sf_cloud_remove_floor(n->scan_tmp));  // :213
+    SF_TRY(sf_bf_set_initial_guess(n->bf, n->map_T_sensor));
+    SF_TRY(sf_bf_set_source_cloud(n->bf, n->scan_tmp));
+    if (!n->coarse_map) SF_TRY(sf_map_create(n->ctx, &n->coarse_map));
+    SF_TRY(sf_map_build(n->coarse_map, n->map_tmp, 0.0f));
+    SF_TRY(sf_bf_set_target_map(n->bf, n->coarse_map));
+    int found = 0;
+    SF_TRY(sf_bf_align_clouds(n->bf, &found));
+    out->coarse_ran = 1;
+    if (!found) {
+        // :221-247 — the ICP keeps this sparse target until the next re-crop, like the reference
+        float best[16];
+        SF_TRY(sf_bf_get_best_transformation(n->bf, best));
+        SF_TRY(sf_icp_set_target_map(n->icp, n->coarse_map));
+        SF_TRY(sf_icp_set_source_cloud(n->icp, n->scan_tmp));
+        SF_TRY(sf_icp_set_initial_transformation(n->icp, best));
+        SF_TRY(sf_icp_set_max_correspondence_dist(n->icp, 5.0f));
+        SF_TRY(sf_icp_set_transformation_epsilon(n->icp, 1e-2f));
+        SF_TRY(sf_icp_set_acceptable_mean_error(n->icp, 0.4f));
+        SF_TRY(sf_icp_set_num_iterations(n->icp, 80));
+        sf_icp_result r;
+        SF_TRY(sf_icp_align(n->icp, SF_ICP_REF_CPP, &r));
+        out->coarse_icp = r;
+        out->coarse_ran = 2;
+        if (r.converged) {
+            SF_TRY(sf_icp_set_max_correspondence_dist(n->icp, 0.5f));
+            SF_TRY(sf_icp_set_transformation_epsilon(n->icp, 1e-5f));
+            SF_TRY(sf_icp_set_acceptable_mean_error(n->icp, 0.05f));
+            SF_TRY(sf_icp_set_num_iterations(n->icp, 10));
+            SF_TRY(sf_bf_reset_first_alignment(n->bf, 1));
+            n->coarse_alignment_complete = true;
+            std::memcpy(n->map_T_sensor, r.T, sizeof(float) * 16);
+            *locked = true;
+            return SF_OK;
+        }
+        SF_TRY(sf_bf_reset_first_alignment(n->bf, 0));
+        return SF_OK;
+    }
+    n->coarse_alignment_complete = true;
+    SF_TRY(sf_bf_get_best_transformation(n->bf, n->map_T_sensor));
+    *locked = true;
+    return SF_OK;
+}
+
+// everything of the callback behind the scan upload
+int callback_body(sf_node *n, const sf_gps_fix *gps, const sf_odom *odom, const float odom_T_sensor_current[16], sf_node_output *out)
+{
+    // PREPROCESSING :290-305
+    SF_TRY(sf_cloud_subsample(n->scan, 2));
+    const float origin[3] = {0.0f, 0.0f, 0.0f};
+    // index order unless asked otherwise: the order of the source points only moves the rounding of the record sums, and
+    // PCL's distance order (point_cloud_processing.hpp:40-52) costs a sort per scan
+    SF_TRY(sf_cloud_crop_radius(n->scan, origin, (double)n->prm.cloud_crop_radius, n->prm.pcl_crop_order ? 1 : 0));
+    float inv[16], sensor_T_ref[16];
+    sf_fusion_mat4f_inverse(n->map_T_sensor, inv);
+    sf_fusion_mat4f_mul(inv, n->map_T_ref, sensor_T_ref);
+    const float dx = sensor_T_ref[3], dy = sensor_T_ref[7], dz = sensor_T_ref[11];
+    if (sqrtf(dx * dx + dy * dy + dz * dz) > n->prm.ref_frame_distance || !n->have_window) {
+        const float c[3] = {n->map_T_sensor[3], n->map_T_sensor[7], n->map_T_sensor[11]};
+        SF_TRY(sf_map_window_sphere(n->map_index, c, (double)n->prm.cloud_crop_radius));
+        SF_TRY(sf_icp_set_target_map(n->icp, n->map_index)); // icp_->setTargetPointCloud(ref_cropped_map_cloud_), :303
+        n->have_ref_cropped = false;
+        std::memcpy(n->map_T_ref, n->map_T_sensor, sizeof(float) * 16);
+        n->have_window = true;
+        out->recropped = 1;
+    }
+
+    // COARSE ALIGNMENT :307-315
+    if (!n->coarse_alignment_complete) {
+        bool locked = false;
+        SF_TRY(coarse_alignment(n, out, &locked));
+        if (!locked) { out->status = SF_NODE_COARSE_FAILED; return SF_OK; }
+    }
+
+    // FINE ALIGNMENT :318-338 — the prior: odometry prediction, GPS/compass pose, covariance-weighted blend, StochasticFilter
+    float map_T_sensor_odom[16], map_T_sensor_gps[16], prior[16], filtered[16];
+    sf_fusion_odom_prediction(n->map_T_sensor, n->odom_T_sensor_previous, odom_T_sensor_current, map_T_sensor_odom);
+    gps_coarse_pose(n, gps->latitude, gps->longitude, map_T_sensor_gps);
+    float odometry_gain = 0.0f, gps_compass_gain = 0.0f;
+    sf_fusion_pose_gains(gps->position_covariance, odom->covariance, 0, &odometry_gain, &gps_compass_gain);
+    sf_fusion_blend(odometry_gain, map_T_sensor_odom, gps_compass_gain, map_T_sensor_gps, prior);
+    sf_sfilter_add_pose_to_queue(n->filter, prior);
+    sf_sfilter_apply_gaussian_filter(n->filter, n->map_T_sensor, prior, filtered);
+    std::memcpy(out->prior, filtered, sizeof(float) * 16);
+    std::memcpy(out->odom_pose, map_T_sensor_odom, sizeof(float) * 16);
+    std::memcpy(out->gps_pose, map_T_sensor_gps, sizeof(float) * 16);
+    out->odometry_gain = odometry_gain;
+    out->gps_compass_gain = gps_compass_gain;
+    SF_TRY(sf_icp_set_source_cloud(n->icp, n->scan));
+    SF_TRY(sf_icp_set_initial_transformation(n->icp, filtered));
+    SF_TRY(sf_icp_align(n->icp, n->prm.icp_mode, &out->icp));
+    std::memcpy(n->map_T_sensor, out->icp.T, sizeof(float) * 16); // no has_converged check, :338
+    std::memcpy(n->odom_T_sensor_previous, odom_T_sensor_current, sizeof(float) * 16); // :341
+    SF_TRY(sf_cloud_size(n->scan, &out->n_scan));
+    std::memcpy(out->map_T_sensor, n->map_T_sensor, sizeof(float) * 16);
+    out->status = SF_NODE_OK;
+    return SF_OK;
+}
+
+// the gates in front of the scan (:269-283); returns true when the callback is over
+bool callback_gates(sf_node *n, const sf_gps_fix *gps, const sf_odom *odom, float odom_T_sensor_current[16], sf_node_output *out)
+{
+    std::memset(out, 0, sizeof(*out));
+    std::memcpy(out->map_T_sensor, n->map_T_sensor, sizeof(float) * 16);
+    if (gps->altitude < 0) { out->status = SF_NODE_GATED_ALTITUDE; return true; } // :269-276
+    sf_fusion_quat_to_pose(odom->q_wxyz, odom->t, odom_T_sensor_current);
+    if (n->first_time) { // :278-283 -> :181-198
+        gps_coarse_pose(n, gps->latitude, gps->longitude, n->map_T_sensor);
+        std::memcpy(n->map_T_ref, n->map_T_sensor, sizeof(float) * 16);
+        std::memcpy(n->odom_T_sensor_previous, odom_T_sensor_current, sizeof(float) * 16);
+        n->first_time = false;
+        std::memcpy(out->map_T_sensor, n->map_T_sensor, sizeof(float) * 16);
+        out->status = SF_NODE_FIRST_MESSAGE;
+        return true;
+    }
+    return false;
+}
+
+} // namespace
+
+extern "C" void sf_node_default_params(sf_node_params *p)
+{
+    if (!p) return;
+    p->ref_frame_distance = 3.0f; // localization_node.h:142
+    p->cloud_crop_radius = 10.0f; // localization_node.h:145
+    p->index_cell = 0.5f;
+    p->pcl_crop_order = 0;
+    p->icp_mode = SF_ICP_REF_CPP;
+    p->map_is_downsampled = 1;
+}
+
+extern "C" int sf_node_create(sf_ctx *ctx, const float *map_xyz, int64_t n_map, const double map_T_global[16], const double *altitude_table_lat_lon_alt, int rows,
+                              const sf_node_params *params, sf_node **out)
+{
+    SF_CHECK(ctx && out && map_T_global && (map_xyz || n_map == 0) && n_map >= 0 && rows >= 0 && (altitude_table_lat_lon_alt || rows == 0), SF_ERR_INVALID, "bad arguments");
+    sf_node *n = new (std::nothrow) sf_node();
+    SF_CHECK(n, SF_ERR_NOMEM, "out of host memory");
+    n->ctx = ctx;
+    if (params) n->prm = *params;
+    else sf_node_default_params(&n->prm);
+    std::memcpy(n->map_T_global, map_T_global, sizeof(double) * 16);
+    if (rows > 0) n->altitude_table.assign(altitude_table_lat_lon_alt, altitude_table_lat_lon_alt + (size_t)rows * 3);
+    eye4(n->map_T_sensor); eye4(n->odom_T_sensor_previous); eye4(n->map_T_ref);
+    int rc = SF_OK;
+    auto step = [&](int r) { if (rc == SF_OK) rc = r; };
+    step(sf_cloud_create(ctx, &n->map_cloud));
+    if (rc == SF_OK) step(sf_cloud_upload(n->map_cloud, map_xyz, n_map));
+    if (rc == SF_OK && !n->prm.map_is_downsampled) step(sf_cloud_voxel_downsample(n->map_cloud, 0.1, SF_VOXEL_PCL, nullptr)); // getMapCloud(0.1f), :19
+    if (rc == SF_OK) step(sf_cloud_subsample(n->map_cloud, 3));                                                            // applyUniformSubsample(map_cloud_, 3), :20
+    if (rc == SF_OK) step(sf_map_create(ctx, &n->map_index));
+    if (rc == SF_OK) step(sf_map_build(n->map_index, n->map_cloud, n->prm.index_cell));
+    if (rc == SF_OK) step(sf_icp_create(ctx, 0.5f, 10, 0.05f, 1e-5f, &n->icp)); // :24-28
+    if (rc == SF_OK) step(sf_icp_set_target_map(n->icp, n->map_index));
+    if (rc == SF_OK) step(sf_icp_use_graph(n->icp, 1));
+    if (rc == SF_OK) {
+        n->filter = sf_sfilter_create(4, 3.0f); // :32-34
+        if (!n->filter) { sf::set_error("sf_sfilter_create failed"); rc = SF_ERR_NOMEM; }
+    }
+    if (rc == SF_OK) step(sf_bf_create(ctx, &n->bf)); // :38-43
+    if (rc == SF_OK) step(sf_bf_set_mean_error_threshold(n->bf, 0.1f));
+    if (rc == SF_OK) step(sf_bf_set_xyz_step(n->bf, 0.1f, 0.1f, 0.05f));
+    if (rc == SF_OK) step(sf_bf_set_xyz_range(n->bf, 1.5f, 1.5f, 0.1f));
+    if (rc == SF_OK) step(sf_bf_set_rotation_step(n->bf, (float)(M_PI / 18.0)));
+    if (rc == SF_OK) step(sf_bf_set_rotation_range(n->bf, (float)(M_PI / 6.0)));
+    if (rc == SF_OK) step(sf_cloud_create(ctx, &n->scan));
+    if (rc != SF_OK) { sf_node_destroy(n); return rc; }
+    *out = n;
+    return SF_OK;
+}
+
+extern "C" void sf_node_destroy(sf_node *n)
+{
+    if (!n) return;
+    if (n->icp) sf_icp_destroy(n->icp);
+    if (n->bf) sf_bf_destroy(n->bf);
+    if (n->filter) sf_sfilter_destroy(n->filter);
+    if (n->coarse_map) sf_map_destroy(n->coarse_map);
+    if (n->map_index) sf_map_destroy(n->map_index);
+    for (sf_cloud *c : {n->map_cloud, n->scan, n->ref_cropped, n->map_tmp, n->scan_tmp})
+        if (c) sf_cloud_destroy(c);
+    delete n;
+}
+
+// compassCallback, localization_node.cpp:62-77
+extern "C" int sf_node_compass(sf_node *n, double compass_deg)
+{
+    SF_CHECK(n, SF_ERR_INVALID, "node is NULL");
+    n->current_compass_yaw = sf_fusion_compass_to_yaw(compass_deg);
+    return SF_OK;
+}
+
+extern "C" int sf_node_callback_xyz(sf_node *n, const float *xyz, int64_t n_points, const sf_gps_fix *gps, const sf_odom *odom, sf_node_output *out)
+{
+    SF_CHECK(n && gps && odom && out && (xyz || n_points == 0) && n_points >= 0, SF_ERR_INVALID, "bad arguments");
+    float odom_T_sensor_current[16];
+    if (callback_gates(n, gps, odom, odom_T_sensor_current, out)) return SF_OK;
+    SF_TRY(sf_cloud_upload(n->scan, xyz, n_points));
+    return callback_body(n, gps, odom, odom_T_sensor_current, out);
+}
+
+// the scan as the sensor_msgs/PointCloud2 the node subscribes to (:51-56), unpacked on the device
+extern "C" int sf_node_callback_pointcloud2(sf_node *n, const void *data, int64_t data_bytes, int64_t width, int64_t height, int point_step, int64_t row_step, int off_x, int off_y,
+                                            int off_z, int datatype, int is_bigendian, const sf_gps_fix *gps, const sf_odom *odom, sf_node_output *out)
+{
+    SF_CHECK(n && gps && odom && out, SF_ERR_INVALID, "bad arguments");
+    float odom_T_sensor_current[16];
+    if (callback_gates(n, gps, odom, odom_T_sensor_current, out)) return SF_OK;
+    SF_TRY(sf_cloud_from_pointcloud2_msg(n->scan, data, data_bytes, width, height, point_step, row_step, off_x, off_y, off_z, datatype, is_bigendian));
+    return callback_body(n, gps, odom, odom_T_sensor_current, out);
+}
+
+// state access for callers that already hold a lock (and for tests): which = SF_NODE_POSE_*
+extern "C" int sf_node_set_pose(sf_node *n, int which, const float T[16])
+{
+    SF_CHECK(n && T, SF_ERR_INVALID, "bad arguments");
+    float *dst = which == SF_NODE_POSE_MAP_T_SENSOR ? n->map_T_sensor : which == SF_NODE_POSE_MAP_T_REF ? n->map_T_ref : which == SF_NODE_POSE_ODOM_PREVIOUS ? n->odom_T_sensor_previous : nullptr;
+    SF_CHECK(dst, SF_ERR_INVALID, "unknown pose %d", which);
+    std::memcpy(dst, T, sizeof(float) * 16);
+    return SF_OK;
+}
+
+extern "C" int sf_node_get_pose(sf_node *n, int which, float T[16])
+{
+    SF_CHECK(n && T, SF_ERR_INVALID, "bad arguments");
+    const float *src = which == SF_NODE_POSE_MAP_T_SENSOR ? n->map_T_sensor : which == SF_NODE_POSE_MAP_T_REF ? n->map_T_ref : which == SF_NODE_POSE_ODOM_PREVIOUS ? n->odom_T_sensor_previous : nullptr;
+    SF_CHECK(src, SF_ERR_INVALID, "unknown pose %d", which);
+    std::memcpy(T, src, sizeof(float) * 16);
+    return SF_OK;
+}
+
+extern "C" int sf_node_set_coarse_alignment_complete(sf_node *n, int complete)
+{
+    SF_CHECK(n, SF_ERR_INVALID, "node is NULL");
+    n->coarse_alignment_complete = complete != 0;
+    return SF_OK;
+}
+
+extern "C" int sf_node_coarse_alignment_complete(sf_node *n) { return n && n->coarse_alignment_complete ? 1 : 0; }
+
+extern "C" sf_icp *sf_node_icp(sf_node *n) { return n ? n->icp : nullptr; }
+extern "C" sf_bf *sf_node_bf(sf_node *n) { return n ? n->bf : nullptr; }

@@ -20,8 +20,8 @@ class LocalizationFlow:
     cloud_crop_radius_ = 10.0
     icp_mode_ = "ref_cpp"              # ICPPointToPoint::calculateAlignment (icp_point_to_point.cpp:185-254)
     # grid cell of the whole-map index: the reference's "d2 < 0.5" rule (icp_point_to_point.cpp:70) is a 0.707 m search
-    # radius on a stride-3 map (0.3 m point spacing); a cell of that size keeps every search inside the 27-cell block
-    # (automatic sizing, 1.5 points per cell, sends each query without a neighbour through a second ring, lane by lane)
+    # radius on a stride-3 map (0.3 m point spacing).  Measured per alignment of ~13 k points (outer rings shared by the
+    # wave, sf_nn.hpp): 0.72 m (every search inside the 27-cell block) 409 us, 0.5 m 349 us, 0.36 m 355 us, 0.25 m 381 us
     index_cell_ = 0.5
     pcl_crop_order_ = False            # True: the scan crop keeps PCL's ascending-distance output order (point_cloud_processing.hpp:40-52)
 
@@ -37,8 +37,9 @@ class LocalizationFlow:
         self.altitude_table_ = np.zeros((0, 3)) if altitude_table is None else np.asarray(altitude_table, dtype=np.float64)
         self.icp_ = api.Icp(ctx, 0.5, 10, 0.05, 1e-5)        # :24-28
         self.icp_.set_target(self.map_index_)
-        # the alignment's ~50 small launches replayed as one hipGraph: the scan's point count and the map crop are read from
-        # device memory by the REF_CPP kernels, so the captured list survives both changing from scan to scan
+        # a per-scan REF_CPP alignment runs as one launch (sf_icp_set_fused, on by default); where that does not apply (scans
+        # too large to be resident at once) the ~50 small launches are replayed as one hipGraph: the scan's point count and the
+        # map crop are read from device memory by those kernels, so the captured list survives both changing from scan to scan
         self.icp_.use_graph(True)
         self.coarse_pose_filter_ = api.StochasticFilter(4, 3.0)   # :32-34
         self.brute_force_alignment_ = api.BruteForceAlignment(ctx)   # :38-43
@@ -173,6 +174,54 @@ class LocalizationFlow:
 
     def after_alignment(self, result, scan):
         pass
+
+
+class NativeLocalizationFlow:
+    """The same orchestration run by the library itself (sf_node_*, csrc/sf_node.cpp): one C call per scan instead of
+    ~25 ctypes calls and their numpy conversions.  Same interface and the same poses, bit for bit, as LocalizationFlow
+    (tests/test_gpu_node.py); what a C++ node would link against."""
+
+    def __init__(self, ctx, map_points, map_T_global, altitude_table=None, map_is_downsampled=True):
+        self.ctx = ctx
+        self.node_ = api.Node(ctx, map_points, map_T_global, altitude_table, index_cell=LocalizationFlow.index_cell_,
+                              pcl_crop_order=int(LocalizationFlow.pcl_crop_order_), icp_mode=LocalizationFlow.icp_mode_,
+                              ref_frame_distance=LocalizationFlow.ref_frame_distance_, cloud_crop_radius=LocalizationFlow.cloud_crop_radius_,
+                              map_is_downsampled=int(map_is_downsampled))
+        self.icp_ = self.node_.icp
+        self.brute_force_alignment_ = self.node_.bf
+        self.last = {}
+
+    map_T_sensor_ = property(lambda self: self.node_.get_pose(api.SF_NODE_POSE_MAP_T_SENSOR), lambda self, T: self.node_.set_pose(api.SF_NODE_POSE_MAP_T_SENSOR, T))
+    map_T_ref_ = property(lambda self: self.node_.get_pose(api.SF_NODE_POSE_MAP_T_REF), lambda self, T: self.node_.set_pose(api.SF_NODE_POSE_MAP_T_REF, T))
+    odom_T_sensor_previous_ = property(lambda self: self.node_.get_pose(api.SF_NODE_POSE_ODOM_PREVIOUS), lambda self, T: self.node_.set_pose(api.SF_NODE_POSE_ODOM_PREVIOUS, T))
+    coarse_alignment_complete_ = property(lambda self: self.node_.coarse_alignment_complete(), lambda self, v: self.node_.set_coarse_alignment_complete(v))
+
+    def compassCallback(self, compass_deg):
+        self.node_.compass(compass_deg)
+
+    def localizationCallback(self, scan_xyz, gps, odom, imu=None):
+        out = self.node_.callback(scan_xyz, gps, odom)
+        self.out_ = out
+        if out.status != api.SF_NODE_OK:
+            return None
+        self.last = _LazyLast(out)
+        return np.array(out.map_T_sensor, dtype=np.float32).reshape(4, 4)
+
+
+class _LazyLast(dict):
+    """flow.last of the native flow: converted from the output structure only when somebody reads it"""
+
+    def __init__(self, out):
+        super().__init__()
+        self._out = out
+
+    def __missing__(self, key):
+        o = self._out
+        m = lambda a: np.array(a, dtype=np.float32).reshape(4, 4)
+        v = {"prior": lambda: m(o.prior), "icp": lambda: o.icp.as_dict(), "n_scan": lambda: int(o.n_scan), "odom": lambda: m(o.odom_pose), "gps": lambda: m(o.gps_pose),
+             "gains": lambda: (float(o.odometry_gain), float(o.gps_compass_gain))}[key]()
+        self[key] = v
+        return v
 
 
 class EkfLocalizationFlow(LocalizationFlow):

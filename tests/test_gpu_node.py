@@ -1,0 +1,114 @@
+"""sf_node_* (csrc/sf_node.cpp): LocalizationNode::localizationCallback (localization_node.cpp:263-344) as one
+library call.  The Python mirror of the same orchestration (localization_flow.LocalizationFlow) is checked against the
+oracle flow in tests/test_adapters.py; here the library's own orchestration must give the same poses BIT FOR BIT -- over a
+stream with re-crops, from a PointCloud2 message, through the gates, and through the start-up lock (brute force, then the
+"strong" ICP)."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from test_adapters import make_sensor_scan
+
+pytestmark = pytest.mark.gpu
+
+
+def messages_for(truth, k, rng, gps_cov, odom_cov):
+    q = Rotation.from_matrix(truth[:3, :3]).as_quat()
+    odom = dict(q_wxyz=[q[3], q[0], q[1], q[2]], t=truth[:3, 3] + rng.normal(0, 0.002, 3), covariance=odom_cov)
+    gps = dict(latitude=-22.9068 + 1e-7 * k, longitude=-43.1729, altitude=12.0, position_covariance=gps_cov)
+    return gps, odom
+
+
+def test_native_node_equals_python_flow_on_a_stream(api, ctx, orc, synth):
+    from slam_sensor_fusion_amd.localization_flow import LocalizationFlow, NativeLocalizationFlow
+    from slam_sensor_fusion_amd.localization_python import messages
+    raw = synth.make_map(400_000, seed=31)
+    ds = orc.voxel_pcl(raw, 0.1)[0]
+    lla0 = np.array([[-22.9068, -43.1729, 12.0], [-22.90681, -43.17291, 12.1], [-22.90679, -43.17289, 11.9]])
+    mtg = orc.map_T_global(lla0, np.zeros(3, np.float32))
+    flows = [LocalizationFlow(ctx, ds, mtg, altitude_table=lla0), NativeLocalizationFlow(ctx, ds, mtg, altitude_table=lla0),
+             NativeLocalizationFlow(ctx, ds, mtg, altitude_table=lla0)]
+    for f in flows:
+        f.coarse_alignment_complete_ = True
+    gps_cov, odom_cov = np.diag([0.25, 0.25, 0.25]).ravel(), np.diag([1e-4] * 6).ravel()
+    rng = np.random.default_rng(5)
+    recrops = 0
+    for k in range(14):
+        truth = synth.make_T((0.45 * k - 3.0, 0.05 * k, 0.0), (0, 0, 1.0 * k))
+        scan = make_sensor_scan(synth, ds, truth, 8000, 100 + k)
+        gps, odom = messages_for(truth, k, rng, gps_cov, odom_cov)
+        if k == 5:                                                       # a dropped message (:269-276) changes nothing
+            bad = dict(gps, altitude=-1.0)
+            before = [f.map_T_sensor_.copy() for f in flows]
+            assert all(f.localizationCallback(scan, bad, odom) is None for f in flows)
+            assert flows[1].out_.status == api.SF_NODE_GATED_ALTITUDE
+            assert all(np.array_equal(f.map_T_sensor_, b) for f, b in zip(flows, before))
+        outs = []
+        for i, f in enumerate(flows):
+            f.compassCallback(90.0 - k)
+            outs.append(f.localizationCallback(messages.PointCloud2(scan) if i == 2 else scan, gps, odom))
+        if k == 0:
+            assert all(o is None for o in outs) and flows[1].out_.status == api.SF_NODE_FIRST_MESSAGE
+            assert np.array_equal(flows[0].map_T_sensor_, flows[1].map_T_sensor_) and np.array_equal(flows[0].odom_T_sensor_previous_, flows[1].odom_T_sensor_previous_)
+            for f in flows:                                              # the float32 UTM pose is metre-level: start from the truth
+                f.map_T_sensor_ = truth.astype(np.float32)
+                f.map_T_ref_ = truth.astype(np.float32)
+            continue
+        py, nat, pc2 = flows
+        for other, o in ((nat, outs[1]), (pc2, outs[2])):
+            assert np.array_equal(outs[0], o), k
+            assert np.array_equal(py.last["prior"], other.last["prior"]) and py.last["n_scan"] == other.last["n_scan"]
+            assert np.array_equal(py.last["odom"], other.last["odom"]) and np.array_equal(py.last["gps"], other.last["gps"]) and py.last["gains"] == other.last["gains"]
+            a, b = py.last["icp"], other.last["icp"]
+            assert np.array_equal(a["T64"], b["T64"]) and all(a[x] == b[x] for x in ("iterations", "converged", "n_corr", "n_research", "error", "flags"))
+            assert np.array_equal(py.map_T_ref_, other.map_T_ref_)
+        recrops += nat.out_.recropped
+        assert synth.pose_error(outs[1], truth)[0] < 0.1
+    assert recrops >= 2                                                  # the 3 m re-crop rule fired
+    assert nat.icp_.fused_count() == 13                                   # every per-scan alignment was one launch
+
+
+@pytest.mark.parametrize("bf_hits", [False, True])
+def test_native_node_start_up_lock_equals_python_flow(api, ctx, orc, synth, bf_hits):
+    """Both orchestrations from scratch: first message, then the coarse phase over the node's full 7 776-candidate pose
+    grid.  On this sparse floor-free map (stride 3 x 15) the node's 0.1 threshold is missed, so the "strong" ICP runs on
+    every scan (bf_hits = False); with the threshold raised above the best score the brute force locks at once."""
+    from slam_sensor_fusion_amd.localization_flow import LocalizationFlow, NativeLocalizationFlow
+    raw = synth.make_map(400_000, seed=41)
+    ds = orc.voxel_pcl(raw, 0.1)[0]
+    lla0 = np.array([[-22.9068, -43.1729, 12.0]])
+    mtg = orc.map_T_global(lla0, np.zeros(1, np.float32))
+    py, nat = LocalizationFlow(ctx, ds, mtg, altitude_table=lla0), NativeLocalizationFlow(ctx, ds, mtg, altitude_table=lla0)
+    if bf_hits:
+        for f in (py, nat):
+            f.brute_force_alignment_.setMeanErrorThreshold(0.6)
+    gps_cov, odom_cov = np.diag([0.25, 0.25, 0.25]).ravel(), np.diag([1e-4] * 6).ravel()
+    rng = np.random.default_rng(9)
+    ran = []
+    for k in range(5):
+        truth = synth.make_T((0.27 + 0.1 * k, -0.14, 0.03), (0, 0, 6.0))
+        scan = make_sensor_scan(synth, ds, truth, 6000, 77 + k)
+        gps, odom = messages_for(truth, k, rng, gps_cov, odom_cov)
+        a, b = py.localizationCallback(scan, gps, odom), nat.localizationCallback(scan, gps, odom)
+        if k == 0:
+            assert a is None and b is None
+            start = np.eye(4, dtype=np.float32)                          # a start pose 0.3 m / 6 degrees off, inside the pose grid
+            for f in (py, nat):
+                f.map_T_sensor_ = start
+                f.map_T_ref_ = start
+            continue
+        assert (a is None) == (b is None), k
+        assert py.coarse_alignment_complete_ == nat.coarse_alignment_complete_
+        assert np.array_equal(py.map_T_sensor_, nat.map_T_sensor_), k
+        ran.append(int(nat.out_.coarse_ran))
+        if nat.out_.coarse_ran == 2:
+            r, o = py.last_coarse["icp"], nat.out_.coarse_icp.as_dict()
+            assert np.array_equal(r["T64"], o["T64"]) and r["iterations"] == o["iterations"] and r["converged"] == o["converged"]
+        if a is not None:
+            assert np.array_equal(a, b)
+    if bf_hits:
+        # locked by the brute force on the first scan (the first candidate under the loose threshold, not the best one:
+        # brute_force_alignment.cpp:107-117 returns at once), fine alignments after
+        assert ran == [1, 0, 0, 0] and nat.coarse_alignment_complete_ and a is not None
+    else:
+        assert ran[0] == 2                                               # brute force missed, the "strong" ICP ran

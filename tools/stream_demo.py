@@ -15,7 +15,7 @@ from scipy.spatial.transform import Rotation
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slam_sensor_fusion_amd import api, synth  # noqa: E402
-from slam_sensor_fusion_amd.localization_flow import EkfLocalizationFlow, ImuEkfMappingFlow, LocalizationFlow  # noqa: E402
+from slam_sensor_fusion_amd.localization_flow import EkfLocalizationFlow, ImuEkfMappingFlow, LocalizationFlow, NativeLocalizationFlow  # noqa: E402
 
 
 def main():
@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--prior", default="reference", choices=["reference", "ekf", "imu-ekf-growth"],
                     help="reference: blend + StochasticFilter (localization_node.cpp:318-332); ekf: the sf_ekf extension, GPS given in the map frame; "
                          "imu-ekf-growth: config 4 as worded -- 15-state EKF fed 100 Hz IMU samples + map growth every 10 scans")
+    ap.add_argument("--python-flow", action="store_true", help="prior 'reference' only: the Python mirror of the orchestration instead of the library's own (sf_node_*)")
     args = ap.parse_args()
     ctx = api.Context(0)
     raw = synth.make_map(args.map_points)
@@ -40,7 +41,8 @@ def main():
     ds[:, 0] += np.float32(L / 2 - 12.0)
     lla0 = np.array([[-22.9068, -43.1729, 12.0]])
     mtg = api.map_T_global(lla0, np.zeros(1, np.float32))
-    flow = {"reference": LocalizationFlow, "ekf": EkfLocalizationFlow, "imu-ekf-growth": ImuEkfMappingFlow}[args.prior](ctx, ds, mtg, altitude_table=lla0)
+    flow = {"reference": LocalizationFlow if args.python_flow else NativeLocalizationFlow, "ekf": EkfLocalizationFlow,
+            "imu-ekf-growth": ImuEkfMappingFlow}[args.prior](ctx, ds, mtg, altitude_table=lla0)
     gyro, accel, imu_dt = synth.make_imu(args.scans)
     flow.coarse_alignment_complete_ = True
     stream = synth.make_stream(args.scans)
@@ -84,7 +86,8 @@ def main():
                       "callback_ms_median": float(np.median(times) * 1e3), "callback_ms_p99": float(np.quantile(times, 0.99) * 1e3),
                       "scans_per_s": float(1.0 / np.mean(times)), "translation_err_m_median": float(np.median(errs)),
                       "translation_err_m_max": float(np.max(errs)), "reference_budget_ms": 100.0,
-                      "graph_captures_and_launches": list(flow.icp_.graph_counts())}))
+                      "orchestration": type(flow).__name__, "graph_captures_and_launches": list(flow.icp_.graph_counts()),
+                      "single_launch_alignments": flow.icp_.fused_count()}))
 
 
 if __name__ == "__main__":
