@@ -211,6 +211,14 @@ int sf_icp_set_debug_mode(sf_icp *icp, int on);
 /* setSourcePointCloud — icp_point_to_point.cpp:44-47 (copies; caller keeps its cloud) */
 int sf_icp_set_source(sf_icp *icp, const float *xyz, int64_t n);
 int sf_icp_set_source_cloud(sf_icp *icp, sf_cloud *cloud);
+/* The node's scan preprocessing and setSourcePointCloud in one pass, without a host synchronisation
+ * (localization_node.cpp:290-297,333): the source becomes every stride-th point of `raw` that is finite and within `radius`
+ * of `center`, in index order -- exactly sf_cloud_subsample(stride) + sf_cloud_crop_radius(center, radius, 0) +
+ * sf_icp_set_source_cloud, same predicates, same points.  `raw` is left untouched; the count stays on the device, so the
+ * source serves unsharded single-scan REF_CPP alignments only.  sf_icp_source_count: the number of points the last fetched
+ * single-scan REF_CPP alignment ran on. */
+int sf_icp_set_source_scan(sf_icp *icp, sf_cloud *raw, int stride, const float center[3], double radius);
+int sf_icp_source_count(sf_icp *icp, int64_t *n);
 /* setTargetPointCloud — icp_point_to_point.cpp:49-55: either index a cloud privately
  * (reference semantics) or share a prebuilt whole-map index (no copy, no rebuild). */
 int sf_icp_set_target(sf_icp *icp, const float *xyz, int64_t n);

@@ -484,6 +484,17 @@ class Icp:
         _check(self.lib.sf_icp_graph_counts(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def set_source_scan(self, raw_cloud, stride, center, radius):
+        """sf_icp_set_source_scan: subsample + radius crop + set_source in one pass, the count stays on the device"""
+        c = _f32(center)
+        _check(self.lib.sf_icp_set_source_scan(self.h, raw_cloud.h, C.c_int(int(stride)), _p(c), C.c_double(radius)))
+        self.batch = 1
+
+    def source_count(self):
+        n = C.c_int64()
+        _check(self.lib.sf_icp_source_count(self.h, C.byref(n)))
+        return n.value
+
     def set_fused(self, on=True):
         _check(self.lib.sf_icp_set_fused(self.h, C.c_int(int(on))))
 

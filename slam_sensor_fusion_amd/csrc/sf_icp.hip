@@ -48,6 +48,7 @@ struct IcpState {
     float step[12];
     int step_pending;
     int iterations, done, research, n_corr, n_research, flags, converged;
+    int n_points, pad_; // single-scan REF_CPP with the count in device memory: the count the alignment ran on (sf_icp_source_count)
     double T_list[12]; // sharded path: the pose this rank's owned-query arrays were built at
 };
 
@@ -455,6 +456,8 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
     for (int i = 0; i < 12; ++i) s.step[i] = 0;
     s.step_pending = 0;
     s.iterations = s.done = s.research = s.n_corr = s.n_research = s.flags = s.converged = 0;
+    s.n_points = -1;
+    s.pad_ = 0;
     for (int i = 0; i < 12; ++i) s.T_list[i] = s.T[i];
     st[b] = s;
 }
@@ -1031,6 +1034,70 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
     if (margin > 0.0f && !S->done) own_check_motion(S, *boxp, margin); // sharded path only (the box of the source batch, computed on the device)
 }
 
+// ------------------------------------------------------------------ the per-scan source in one pass
+// The node's preprocessing of a scan (localization_node.cpp:290-297: applyUniformSubsample(2), cropPointCloudThroughRadius
+// around the sensor) and setSourcePointCloud as two launches with no host synchronisation between the upload and the
+// alignment: the same predicates as sf_cloud_subsample + sf_cloud_crop_radius (every stride-th point; finite and FLANN
+// L2_Simple d2 < r2, unfused float32), the survivors in index order written straight into the alignment's source arrays,
+// their count left in device memory (the REF_CPP kernels bound themselves by it).  Measured on the per-scan path: the
+// separate operations are 9 launches and a host synchronisation (the count sizes the next launch) = ~100 us between
+// the upload and the alignment for ~25 us of device work.
+__device__ __forceinline__ bool prep_keep(const float *__restrict__ raw, int64_t n_raw, int stride, int64_t c, int64_t n_cand, float cx, float cy, float cz, float r2, float &x,
+                                          float &y, float &z)
+{
+    if (c >= n_cand) return false;
+    const int64_t i = c * stride;
+    (void)n_raw;
+    x = raw[3 * i]; y = raw[3 * i + 1]; z = raw[3 * i + 2];
+    const bool fin = isfinite(x) && isfinite(y) && isfinite(z);
+    const float dx = cx - x, dy = cy - y, dz = cz - z; // k_flag_radius of sf_cloud.hip, to the letter
+    float d2 = dx * dx;
+    d2 = d2 + dy * dy;
+    d2 = d2 + dz * dz;
+    return fin && d2 < r2;
+}
+
+__global__ __launch_bounds__(BLK) void k_prep_count(const float *__restrict__ raw, int64_t n_raw, int stride, int64_t n_cand, float cx, float cy, float cz, float r2,
+                                                    uint32_t *__restrict__ blk_count)
+{
+    float x, y, z;
+    const bool keep = prep_keep(raw, n_raw, stride, (int64_t)blockIdx.x * BLK + threadIdx.x, n_cand, cx, cy, cz, r2, x, y, z);
+    __shared__ uint32_t wsum[BLK / 64];
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(BLK) void k_prep_scatter(const float *__restrict__ raw, int64_t n_raw, int stride, int64_t n_cand, float cx, float cy, float cz, float r2,
+                                                      const uint32_t *__restrict__ blk_count, float *__restrict__ X0x, float *__restrict__ X0y, float *__restrict__ X0z,
+                                                      float4 *__restrict__ rec, int *__restrict__ n_out)
+{
+    // workgroups before this one (a few hundred at most: every workgroup adds them up itself, in integers)
+    __shared__ uint32_t red[BLK / 64];
+    __shared__ uint32_t wsum[BLK / 64];
+    uint32_t before = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += BLK) before += blk_count[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = before;
+    float x = 0.0f, y = 0.0f, z = 0.0f;
+    const bool keep = prep_keep(raw, n_raw, stride, (int64_t)blockIdx.x * BLK + threadIdx.x, n_cand, cx, cy, cz, r2, x, y, z);
+    const unsigned long long m = __ballot(keep);
+    const uint32_t lane_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    const int wv = threadIdx.x >> 6;
+    uint32_t base = red[0] + red[1] + red[2] + red[3];
+    for (int k = 0; k < wv; ++k) base += wsum[k];
+    if (keep) {
+        const uint32_t o = base + lane_rank;
+        X0x[o] = x; X0y[o] = y; X0z[o] = z;
+        rec[o] = make_float4(x, y, z, 0.0f);
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = (int)(red[0] + red[1] + red[2] + red[3] + wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+
 // ------------------------------------------------------------------ REF_CPP mode
 // X <- init * X0 in float32, unfused, exactly icp_point_to_point.cpp:99-110,191-192
 // n_live (single-scan alignments): the scan's point count read from device memory, so that a captured launch list
@@ -1039,11 +1106,12 @@ __global__ void k_set_int(int *__restrict__ p, int v) { *p = v; }
 __global__ void k_set_window(SfWindow *__restrict__ p, SfWindow w) { *p = w; }
 
 __global__ void k_ref_init(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n, const int *__restrict__ n_live,
-                           const IcpState *__restrict__ st, float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz, int32_t *__restrict__ corr)
+                           IcpState *__restrict__ st, float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz, int32_t *__restrict__ corr)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (n_live) n = *n_live;
+    if (i == 0) st[b].n_points = n; // nobody else touches this field
     if (i >= n) return;
     const IcpState *S = st + b;
     float T[12];
@@ -1246,9 +1314,11 @@ __device__ __forceinline__ bool ref_grid_barrier(uint32_t *ctr, uint32_t target,
 
 template <bool WINDOW>
 __global__ __launch_bounds__(BLK) void k_ref_fused(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
-                                                   IcpState *__restrict__ st, IcpParams prm, float thr, double *__restrict__ partials, int nblocks, uint32_t *__restrict__ bar)
+                                                   const int *__restrict__ n_live, IcpState *__restrict__ st, IcpParams prm, float thr, double *__restrict__ partials, int nblocks,
+                                                   uint32_t *__restrict__ bar)
 {
     const int b = blockIdx.y, bx = blockIdx.x;
+    if (n_live) n = *n_live; // single scan whose count was left on the device (sf_icp_set_source_scan)
     __shared__ IcpState S;
     __shared__ double rec[REC_STRIDE];
     __shared__ sf::WaveNN nn_ws[BLK / 64];
@@ -1256,6 +1326,7 @@ __global__ __launch_bounds__(BLK) void k_ref_fused(SfGrid g, SfWindow w, const f
     static_assert(sizeof(IcpState) % 4 == 0, "copied word by word");
     for (int k = threadIdx.x; k < (int)(sizeof(IcpState) / 4); k += BLK) reinterpret_cast<uint32_t *>(&S)[k] = reinterpret_cast<const uint32_t *>(st + b)[k];
     __syncthreads();
+    if (threadIdx.x == 0) S.n_points = n;
     uint32_t *ctr = bar + 2 * b, *fin = bar + 2 * b + 1;
     double *slab = partials + (size_t)b * nblocks * REC_STRIDE;
     const int i = bx * BLK + (int)threadIdx.x;
@@ -1378,6 +1449,7 @@ struct sf_icp {
     bool ordered = false;    // this alignment reads Xq
     sf::DevBuf corr;         // int32 [B*n] (REF_CPP)
     int64_t n = 0;           // points per scan
+    bool n_on_device = false; // sf_icp_set_source_scan: n is an upper bound, the count itself is in n_dev (single scan, REF_CPP)
     int64_t n_cap = 0;       // single scan: n rounded up (launch geometry of the REF_CPP kernels)
     int64_t plane = 0;       // component stride of the SoA arrays X0 / X / Xq
     sf::DevBuf n_dev;        // the point count in device memory (single-scan REF_CPP kernels read it)
@@ -1526,7 +1598,7 @@ int order_queries(sf_icp *icp, int mode)
     const int64_t total = icp->n * icp->batch;
     const bool want = icp->order == SF_ORDER_CELL || (icp->order == SF_ORDER_AUTO && total >= ORDER_AUTO_MIN_QUERIES);
     icp->ordered = false;
-    if (!want || total == 0 || icp->map->grid.n == 0) return SF_OK;
+    if (!want || total == 0 || icp->map->grid.n == 0 || icp->n_on_device) return SF_OK; // (a count left on the device: the tail of the arrays is not data)
     SF_TRY(run_order_sort(icp, icp->batch, icp->n, total, nullptr, nullptr));
     icp->ordered = true;
     return SF_OK;
@@ -1563,6 +1635,7 @@ int icp_alloc(sf_icp *icp, int64_t n, int batch)
 int icp_set_source_device_aos(sf_icp *icp, const float *d_aos, int64_t n, int batch)
 {
     SF_TRY(icp_alloc(icp, n, batch));
+    icp->n_on_device = false;
     const int64_t total = n * batch;
     if (total > 0)
         hipLaunchKernelGGL(k_soa_from_aos, dim3(nblk(total)), dim3(256), 0, icp->ctx->stream, d_aos, total, soa(icp->X0, icp->plane, 0), soa(icp->X0, icp->plane, 1),
@@ -1776,11 +1849,12 @@ int launch_fused(sf_icp *icp)
     const dim3 grid((unsigned)icp->nblocks, (unsigned)B);
     const float thr = icp->prm.max_corr; // squared-vs-unsquared quirk, icp_point_to_point.cpp:70
     IcpParams prm = icp->prm;
+    const int *nl = icp->n_on_device ? icp->n_dev.as<int>() : nullptr;
     if (m->window.kind != 0)
-        hipLaunchKernelGGL(k_ref_fused<true>, grid, dim3(BLK), 0, s, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n, icp->state.as<IcpState>(), prm, thr,
+        hipLaunchKernelGGL(k_ref_fused<true>, grid, dim3(BLK), 0, s, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n, nl, icp->state.as<IcpState>(), prm, thr,
                            icp->partials.as<double>(), icp->nblocks, icp->bar.as<uint32_t>());
     else
-        hipLaunchKernelGGL(k_ref_fused<false>, grid, dim3(BLK), 0, s, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n, icp->state.as<IcpState>(), prm, thr,
+        hipLaunchKernelGGL(k_ref_fused<false>, grid, dim3(BLK), 0, s, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n, nl, icp->state.as<IcpState>(), prm, thr,
                            icp->partials.as<double>(), icp->nblocks, icp->bar.as<uint32_t>());
     SF_HIP(hipGetLastError());
     icp->fused_launches += 1;
@@ -1809,6 +1883,7 @@ int check_ready(sf_icp *icp, int mode)
     SF_CHECK(icp->have_source, SF_ERR_STATE, "no source cloud set");
     SF_CHECK(icp->map && icp->map->built, SF_ERR_STATE, "no target set");
     SF_CHECK(mode != SF_ICP_P2PLANE || icp->map->has_normals, SF_ERR_STATE, "point-to-plane needs map normals (sf_map_estimate_normals)");
+    SF_CHECK(!icp->n_on_device || (mode == SF_ICP_REF_CPP && !icp->shard), SF_ERR_STATE, "a source set by sf_icp_set_source_scan serves unsharded REF_CPP alignments only");
     SF_CHECK(icp->prm.num_iters >= 0, SF_ERR_INVALID, "negative iteration count");
     return SF_OK;
 }
@@ -1940,6 +2015,45 @@ extern "C" int sf_icp_set_source_batch_device(sf_icp *icp, const void *d_xyz, in
 }
 
 extern "C" int sf_icp_set_source(sf_icp *icp, const float *xyz, int64_t n) { return sf_icp_set_source_batch(icp, xyz, n, 1); }
+
+// the node's scan preprocessing + setSourcePointCloud in one pass (see k_prep_count): `raw` is left as it is
+extern "C" int sf_icp_set_source_scan(sf_icp *icp, sf_cloud *raw, int stride, const float center[3], double radius)
+{
+    SF_CHECK(icp && raw && center && stride > 0 && radius >= 0, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(raw->ctx == icp->ctx, SF_ERR_INVALID, "cloud and icp live on different contexts");
+    SF_CHECK(!icp->shard, SF_ERR_STATE, "not for the sharded path");
+    SF_HIP(hipSetDevice(icp->ctx->device));
+    const int64_t n_raw = raw->n;
+    if (n_raw < stride) stride = 1; // point_cloud_processing.hpp:58-61: a cloud shorter than the step is left untouched
+    const int64_t n_cand = sf::div_up(n_raw, stride);
+    SF_CHECK(n_cand < ((int64_t)1 << 31) - 4096, SF_ERR_OVERFLOW, "too many points");
+    SF_TRY(icp_alloc(icp, n_cand, 1)); // capacity: every candidate survives
+    SF_TRY(icp->n_dev.reserve(sizeof(int)));
+    hipStream_t s = icp->ctx->stream;
+    if (n_cand == 0) {
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, icp->n_dev.as<int>(), 0);
+    } else {
+        const unsigned nb = nblk(n_cand, BLK);
+        SF_TRY(icp->own_blk.reserve(sizeof(uint32_t) * (size_t)nb));
+        const float r2 = (float)(radius * radius);
+        hipLaunchKernelGGL(k_prep_count, dim3(nb), dim3(BLK), 0, s, raw->xyz.as<float>(), n_raw, stride, n_cand, center[0], center[1], center[2], r2, icp->own_blk.as<uint32_t>());
+        hipLaunchKernelGGL(k_prep_scatter, dim3(nb), dim3(BLK), 0, s, raw->xyz.as<float>(), n_raw, stride, n_cand, center[0], center[1], center[2], r2, icp->own_blk.as<uint32_t>(),
+                           soa(icp->X0, icp->plane, 0), soa(icp->X0, icp->plane, 1), soa(icp->X0, icp->plane, 2), icp->X0r.as<float4>(), icp->n_dev.as<int>());
+    }
+    SF_HIP(hipGetLastError());
+    icp->n_on_device = true;
+    icp->have_source = true;
+    return SF_OK;
+}
+
+// points the last single-scan REF_CPP alignment ran on (after sf_icp_align / sf_icp_fetch_results): what sf_icp_set_source_scan kept
+extern "C" int sf_icp_source_count(sf_icp *icp, int64_t *n)
+{
+    SF_CHECK(icp && n, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(icp->batch == 1 && !icp->h_state.empty() && icp->h_state[0].n_points >= 0, SF_ERR_STATE, "no single-scan REF_CPP alignment has been fetched");
+    *n = icp->h_state[0].n_points;
+    return SF_OK;
+}
 
 extern "C" int sf_icp_set_source_cloud(sf_icp *icp, sf_cloud *cloud)
 {

@@ -116,11 +116,17 @@ int coarse_alignment(sf_node *n, sf_node_output *out, bool *locked)
 int callback_body(sf_node *n, const sf_gps_fix *gps, const sf_odom *odom, const float odom_T_sensor_current[16], sf_node_output *out)
 {
     // PREPROCESSING :290-305
-    SF_TRY(sf_cloud_subsample(n->scan, 2));
     const float origin[3] = {0.0f, 0.0f, 0.0f};
-    // index order unless asked otherwise: the order of the source points only moves the rounding of the record sums, and
-    // PCL's distance order (point_cloud_processing.hpp:40-52) costs a sort per scan
-    SF_TRY(sf_cloud_crop_radius(n->scan, origin, (double)n->prm.cloud_crop_radius, n->prm.pcl_crop_order ? 1 : 0));
+    // with the lock held the stride-2 subsample, the radius crop and setSourcePointCloud are one pass on the device with
+    // no host synchronisation (sf_icp_set_source_scan: same points, same order); the coarse phase needs the cropped scan
+    // as a cloud of its own and takes the separate operations
+    const bool one_pass = n->coarse_alignment_complete && n->prm.icp_mode == SF_ICP_REF_CPP && !n->prm.pcl_crop_order;
+    if (!one_pass) {
+        SF_TRY(sf_cloud_subsample(n->scan, 2));
+        // index order unless asked otherwise: the order of the source points only moves the rounding of the record sums, and
+        // PCL's distance order (point_cloud_processing.hpp:40-52) costs a sort per scan
+        SF_TRY(sf_cloud_crop_radius(n->scan, origin, (double)n->prm.cloud_crop_radius, n->prm.pcl_crop_order ? 1 : 0));
+    }
     float inv[16], sensor_T_ref[16];
     sf_fusion_mat4f_inverse(n->map_T_sensor, inv);
     sf_fusion_mat4f_mul(inv, n->map_T_ref, sensor_T_ref);
@@ -156,12 +162,14 @@ int callback_body(sf_node *n, const sf_gps_fix *gps, const sf_odom *odom, const 
     std::memcpy(out->gps_pose, map_T_sensor_gps, sizeof(float) * 16);
     out->odometry_gain = odometry_gain;
     out->gps_compass_gain = gps_compass_gain;
-    SF_TRY(sf_icp_set_source_cloud(n->icp, n->scan));
+    if (one_pass) SF_TRY(sf_icp_set_source_scan(n->icp, n->scan, 2, origin, (double)n->prm.cloud_crop_radius));
+    else SF_TRY(sf_icp_set_source_cloud(n->icp, n->scan));
     SF_TRY(sf_icp_set_initial_transformation(n->icp, filtered));
     SF_TRY(sf_icp_align(n->icp, n->prm.icp_mode, &out->icp));
     std::memcpy(n->map_T_sensor, out->icp.T, sizeof(float) * 16); // no has_converged check, :338
     std::memcpy(n->odom_T_sensor_previous, odom_T_sensor_current, sizeof(float) * 16); // :341
-    SF_TRY(sf_cloud_size(n->scan, &out->n_scan));
+    if (one_pass) SF_TRY(sf_icp_source_count(n->icp, &out->n_scan));
+    else SF_TRY(sf_cloud_size(n->scan, &out->n_scan));
     std::memcpy(out->map_T_sensor, n->map_T_sensor, sizeof(float) * 16);
     out->status = SF_NODE_OK;
     return SF_OK;

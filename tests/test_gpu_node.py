@@ -112,3 +112,61 @@ def test_native_node_start_up_lock_equals_python_flow(api, ctx, orc, synth, bf_h
         assert ran == [1, 0, 0, 0] and nat.coarse_alignment_complete_ and a is not None
     else:
         assert ran[0] == 2                                               # brute force missed, the "strong" ICP ran
+
+
+def test_source_scan_one_pass_equals_separate_operations(api, ctx, orc, synth, small_world):
+    """sf_icp_set_source_scan = sf_cloud_subsample + sf_cloud_crop_radius + sf_icp_set_source_cloud (a1, a2, a7) in one
+    pass with the count left on the device: same points in the same order, hence the same alignment bit for bit -- as one
+    launch and as the launch list; the count comes back with the result; non-finite points, clouds shorter than the
+    stride and empty crops behave like the separate operations."""
+    m = small_world["map"]
+    mp = api.Map(ctx, api.Cloud(ctx, m), 0.25)
+    rng = np.random.default_rng(3)
+    keys = ("iterations", "converged", "n_corr", "n_research", "flags", "error")
+    for case, (n_raw, stride, radius, center) in enumerate([(20001, 2, 3.0, (0.0, 0.0, 0.0)), (9000, 3, 2.2, (0.4, -0.3, 0.1)), (700, 1, 50.0, (0, 0, 0)), (5, 7, 50.0, (0, 0, 0)),
+                                                             (4000, 2, 0.01, (90.0, 0, 0))]):
+        raw = synth.make_scan(m, n_raw, scan_id=200 + case)[0]
+        if case == 0:
+            raw[rng.choice(n_raw, 50, replace=False), rng.integers(0, 3, 50)] = np.nan
+            raw[17] = np.inf
+        ref = api.Cloud(ctx, raw).subsample(stride).crop_radius(center, radius)
+        sub = orc.uniform_subsample(raw, stride)
+        o_pts = sub[np.sort(orc.crop_radius(sub, center, radius)[1])]   # the oracle returns PCL's distance order; index order here
+        assert np.array_equal(ref.download(), o_pts)
+        init = synth.make_T((0.02, -0.01, 0.0), (0, 0.01, 0.2)).astype(np.float32)
+        res = []
+        for one_pass in (False, True):
+            for fused in (True, False):
+                icp = api.Icp(ctx, 0.5, 10, 0.001, 1e-5)
+                icp.set_fused(fused)
+                icp.set_target(mp)
+                cloud = api.Cloud(ctx, raw)
+                if one_pass:
+                    icp.set_source_scan(cloud, stride, center, radius)
+                    assert len(cloud) == n_raw and np.array_equal(cloud.download(), raw, equal_nan=True)   # the raw cloud is untouched
+                else:
+                    icp.set_source(ref)
+                icp.set_initial_transformation(init)
+                r = icp.align("ref_cpp")
+                assert icp.source_count() == len(o_pts)
+                res.append(r)
+                if one_pass and len(o_pts) >= 10:
+                    with pytest.raises(api.SlamFusionError):
+                        icp.align("o3d_p2p")                             # the count is not on the host: REF_CPP only
+                    icp.set_source(ref)                                  # an ordinary source afterwards works as before
+                    assert np.array_equal(icp.align("o3d_p2p")["T64"], api_o3d(api, ctx, mp, ref, init)["T64"])
+        for r in res[1:]:
+            assert np.array_equal(r["T64"], res[0]["T64"]) and all(r[k] == res[0][k] for k in keys), case
+        if len(o_pts) >= 10:
+            o = orc.icp_ref_cpp(o_pts, m, init, 0.5, 10, 0.001, 1e-5, precise=True)
+            assert res[0]["iterations"] == o["iterations"] and res[0]["n_corr"] == o["n_corr"]
+        else:
+            assert res[0]["flags"] & api.SF_ICP_FLAG_FEW_CORR and res[0]["iterations"] == 0
+
+
+def api_o3d(api, ctx, mp, cloud, init):
+    icp = api.Icp(ctx, 0.5, 10, 0.001, 1e-5)
+    icp.set_target(mp)
+    icp.set_source(cloud)
+    icp.set_initial_transformation(init)
+    return icp.align("o3d_p2p")
