@@ -17,23 +17,41 @@ namespace {
 
 inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)sf::div_up(n > 0 ? n : 1, b); }
 
-struct GridGeom { float org[3]; float inv_h; int dim[3]; uint32_t ncell; };
+struct GridGeom { float org[3]; float inv_h; int dim[3]; uint64_t ncell; };
 
-__global__ void k_cell_keys(const float *__restrict__ xyz, int64_t n, GridGeom g, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+// K = uint32_t while the grid has fewer than 2^32 cells, uint64_t beyond (large sparse extents: a dense table over
+// 1 km x 1 km x 100 m at 0.25 m is 6.4e9 cells = 25.6 GB of the 288 GB)
+template <class K>
+__global__ void k_cell_keys(const float *__restrict__ xyz, int64_t n, GridGeom g, K *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    uint32_t key = g.ncell; // non-finite points sort last and are not indexed (PCL drops them too)
+    K key = (K)g.ncell; // non-finite points sort last and are not indexed (PCL drops them too)
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
         int cx = (int)fminf(fmaxf(floorf((x - g.org[0]) * g.inv_h), 0.0f), (float)(g.dim[0] - 1));
         int cy = (int)fminf(fmaxf(floorf((y - g.org[1]) * g.inv_h), 0.0f), (float)(g.dim[1] - 1));
         int cz = (int)fminf(fmaxf(floorf((z - g.org[2]) * g.inv_h), 0.0f), (float)(g.dim[2] - 1));
-        key = ((uint32_t)cz * (uint32_t)g.dim[1] + (uint32_t)cy) * (uint32_t)g.dim[0] + (uint32_t)cx;
+        key = ((K)cz * (K)g.dim[1] + (K)cy) * (K)g.dim[0] + (K)cx;
     }
     keys[i] = key;
     vals[i] = (uint32_t)i;
 }
+
+// Large tables: a point must not fill the empty cells in front of it one by one (a gap can be billions of cells).  The
+// END of every non-empty cell is written to the entry of the cell after it (t[key + 1] = position after the run), the
+// rest stays 0, and an inclusive MAX scan turns that into cell_start: the largest end among the cells before c is the
+// first sorted position whose key is >= c.
+template <class K>
+__global__ void k_cell_tails(const K *__restrict__ keys, int64_t n_valid, uint32_t *__restrict__ cell_start)
+{
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_valid) return;
+    const K k = keys[j];
+    if (j == n_valid - 1 || keys[j + 1] != k) cell_start[(size_t)k + 1] = (uint32_t)(j + 1);
+}
+
+__global__ void k_carry_max(uint32_t *__restrict__ p) { p[0] = max(p[0], p[-1]); }
 
 __global__ void k_gather_sorted(const float *__restrict__ xyz, const uint32_t *__restrict__ vals, int64_t n, float4 *__restrict__ pts4, uint32_t *__restrict__ inv_perm)
 {
@@ -44,7 +62,7 @@ __global__ void k_gather_sorted(const float *__restrict__ xyz, const uint32_t *_
     inv_perm[i] = (uint32_t)j;
 }
 
-// cell_start[c] = first sorted position whose key >= c, for c in [0, ncell]
+// cell_start[c] = first sorted position whose key >= c, for c in [0, ncell] (tables below 2^28 cells: the gaps are short)
 __global__ void k_cell_bounds(const uint32_t *__restrict__ keys, int64_t n_valid, uint32_t ncell, uint32_t *__restrict__ cell_start)
 {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,6 +152,12 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
         h = std::cbrt(1.5 * vol / (double)std::max<int64_t>(n_valid, 1));
         h = std::min(std::max(h, 0.05), 1.0e6);
     }
+    // the dense cell table may take a quarter of what the device has free (288 GB HBM: a 1 km x 1 km x 100 m extent at
+    // 0.25 m is 6.4e9 cells = 25.6 GB), never more than 2^35 cells; automatic sizing grows the cell until it fits, an
+    // explicit cell that does not fit is refused
+    size_t free_b = 0, total_b = 0;
+    SF_HIP(hipMemGetInfo(&free_b, &total_b));
+    const double max_cells = std::min(34359738368.0, std::max(1.0e9, (double)free_b / 4.0 / sizeof(uint32_t)));
     int dim[3];
     for (;;) {
         double cells = 1;
@@ -144,44 +168,75 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
             dim[d] = ok ? (int)c : 1;
             cells *= c;
         }
-        if (ok && cells <= 1.0e9) break; // cell table <= 4 GB
-        SF_CHECK(cell <= 0, SF_ERR_OVERFLOW, "cell %.4g gives too many cells for this extent", (double)cell);
+        if (ok && cells <= max_cells) break;
+        SF_CHECK(cell <= 0, SF_ERR_OVERFLOW, "cell %.4g gives too many cells for this extent (%.3g; this device holds a table of %.3g)", (double)cell, cells, max_cells);
         h *= 1.5;
     }
     GridGeom g;
     for (int d = 0; d < 3; ++d) { g.org[d] = n_valid > 0 ? mm.mn[d] : 0.0f; g.dim[d] = dim[d]; }
     g.inv_h = (float)(1.0 / h);
-    g.ncell = (uint32_t)((uint64_t)dim[0] * dim[1] * dim[2]);
+    g.ncell = (uint64_t)dim[0] * (uint64_t)dim[1] * (uint64_t)dim[2];
+    const bool wide = g.ncell >= 0xffffffffull;     // keys (cell ids, ncell itself for non-finite points) no longer fit 32 bits
+    const bool by_scan = g.ncell > (1ull << 28);    // table large enough for long empty stretches: bounds by scan
 
     // 3. keys -> stable radix sort -> gather
-    SF_TRY(m->keys.reserve(sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)));
-    SF_TRY(m->vals.reserve(sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)));
-    SF_TRY(m->keys2.reserve(sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)));
-    SF_TRY(m->vals2.reserve(sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)));
-    SF_TRY(m->pts4.reserve(sizeof(float4) * (size_t)std::max<int64_t>(n, 1)));
-    SF_TRY(m->inv_perm.reserve(sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)));
+    const size_t np = (size_t)std::max<int64_t>(n, 1), ksz = wide ? sizeof(uint64_t) : sizeof(uint32_t);
+    SF_TRY(m->keys.reserve(ksz * np));
+    SF_TRY(m->vals.reserve(sizeof(uint32_t) * np));
+    SF_TRY(m->keys2.reserve(ksz * np));
+    SF_TRY(m->vals2.reserve(sizeof(uint32_t) * np));
+    SF_TRY(m->pts4.reserve(sizeof(float4) * np));
+    SF_TRY(m->inv_perm.reserve(sizeof(uint32_t) * np));
     SF_TRY(m->cell_start.reserve(sizeof(uint32_t) * ((size_t)g.ncell + 8))); // [pad | start[0..ncell] | pad..]: sf_nn.hpp reads start[c-1..c+2] in one load
     if (n > 0) {
-        hipLaunchKernelGGL(k_cell_keys, dim3(nblk(n)), dim3(256), 0, st, xyz, n, g, m->keys.as<uint32_t>(), m->vals.as<uint32_t>());
         unsigned bits = 1;
-        while (bits < 32 && (1ull << bits) <= (unsigned long long)g.ncell) ++bits;
+        while (bits < 64 && (1ull << bits) <= (unsigned long long)g.ncell) ++bits;
         size_t tmp = 0;
-        hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, m->keys.as<uint32_t>(), m->keys2.as<uint32_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(),
-                                                 (size_t)n, 0, bits, st);
-        SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs(size): %s", hipGetErrorString(e));
-        SF_TRY(sf::ensure_scratch(ctx, tmp));
-        e = rocprim::radix_sort_pairs(ctx->scratch.p, tmp, m->keys.as<uint32_t>(), m->keys2.as<uint32_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), (size_t)n,
-                                      0, bits, st);
+        hipError_t e;
+        if (wide) {
+            hipLaunchKernelGGL(k_cell_keys<uint64_t>, dim3(nblk(n)), dim3(256), 0, st, xyz, n, g, m->keys.as<uint64_t>(), m->vals.as<uint32_t>());
+            e = rocprim::radix_sort_pairs(nullptr, tmp, m->keys.as<uint64_t>(), m->keys2.as<uint64_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), (size_t)n, 0, bits, st);
+            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs(size): %s", hipGetErrorString(e));
+            SF_TRY(sf::ensure_scratch(ctx, tmp));
+            e = rocprim::radix_sort_pairs(ctx->scratch.p, tmp, m->keys.as<uint64_t>(), m->keys2.as<uint64_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), (size_t)n, 0, bits, st);
+        } else {
+            hipLaunchKernelGGL(k_cell_keys<uint32_t>, dim3(nblk(n)), dim3(256), 0, st, xyz, n, g, m->keys.as<uint32_t>(), m->vals.as<uint32_t>());
+            e = rocprim::radix_sort_pairs(nullptr, tmp, m->keys.as<uint32_t>(), m->keys2.as<uint32_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), (size_t)n, 0, bits, st);
+            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs(size): %s", hipGetErrorString(e));
+            SF_TRY(sf::ensure_scratch(ctx, tmp));
+            e = rocprim::radix_sort_pairs(ctx->scratch.p, tmp, m->keys.as<uint32_t>(), m->keys2.as<uint32_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), (size_t)n, 0, bits, st);
+        }
         SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n)), dim3(256), 0, st, xyz, m->vals2.as<uint32_t>(), n, m->pts4.as<float4>(), m->inv_perm.as<uint32_t>());
     }
     uint32_t *cs = m->cell_start.as<uint32_t>() + 1;
-    hipLaunchKernelGGL(k_fill_u32, dim3(nblk((int64_t)g.ncell + 8)), dim3(256), 0, st, m->cell_start.as<uint32_t>(), (int64_t)g.ncell + 8, (uint32_t)n_valid);
-    SF_HIP(hipMemsetAsync(m->cell_start.p, 0, sizeof(uint32_t), st));
-    if (n_valid > 0)
-        hipLaunchKernelGGL(k_cell_bounds, dim3(nblk(n_valid)), dim3(256), 0, st, m->keys2.as<uint32_t>(), n_valid, g.ncell, cs);
-    else
-        hipLaunchKernelGGL(k_fill_u32, dim3(nblk((int64_t)g.ncell + 2)), dim3(256), 0, st, cs, (int64_t)g.ncell + 2, 0u);
+    if (by_scan && n_valid > 0) {
+        // [pad = 0 | t[0..ncell] | pads]: ends of the non-empty cells, then an inclusive max scan in pieces of 2^30 entries
+        // (the carry is the entry before the piece); the trailing pads come out as n_valid like the rest of the tail
+        const size_t entries = (size_t)g.ncell + 8;
+        SF_HIP(hipMemsetAsync(m->cell_start.p, 0, sizeof(uint32_t) * entries, st));
+        if (wide) hipLaunchKernelGGL(k_cell_tails<uint64_t>, dim3(nblk(n_valid)), dim3(256), 0, st, m->keys2.as<uint64_t>(), n_valid, cs);
+        else hipLaunchKernelGGL(k_cell_tails<uint32_t>, dim3(nblk(n_valid)), dim3(256), 0, st, m->keys2.as<uint32_t>(), n_valid, cs);
+        const size_t piece = (size_t)1 << 30;
+        uint32_t *t = m->cell_start.as<uint32_t>();
+        for (size_t off = 0; off < entries; off += piece) {
+            const size_t len = std::min(piece, entries - off);
+            if (off > 0) hipLaunchKernelGGL(k_carry_max, dim3(1), dim3(1), 0, st, t + off);
+            size_t tmp = 0;
+            hipError_t e = rocprim::inclusive_scan(nullptr, tmp, t + off, t + off, len, rocprim::maximum<uint32_t>(), st);
+            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "inclusive_scan(size): %s", hipGetErrorString(e));
+            SF_TRY(sf::ensure_scratch(ctx, tmp));
+            e = rocprim::inclusive_scan(ctx->scratch.p, tmp, t + off, t + off, len, rocprim::maximum<uint32_t>(), st);
+            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "inclusive_scan: %s", hipGetErrorString(e));
+        }
+    } else {
+        hipLaunchKernelGGL(k_fill_u32, dim3(nblk((int64_t)g.ncell + 8)), dim3(256), 0, st, m->cell_start.as<uint32_t>(), (int64_t)g.ncell + 8, (uint32_t)n_valid);
+        SF_HIP(hipMemsetAsync(m->cell_start.p, 0, sizeof(uint32_t), st));
+        if (n_valid > 0)
+            hipLaunchKernelGGL(k_cell_bounds, dim3(nblk(n_valid)), dim3(256), 0, st, m->keys2.as<uint32_t>(), n_valid, (uint32_t)g.ncell, cs);
+        else
+            hipLaunchKernelGGL(k_fill_u32, dim3(nblk((int64_t)g.ncell + 2)), dim3(256), 0, st, cs, (int64_t)g.ncell + 2, 0u);
+    }
     SF_HIP(hipGetLastError());
     SF_HIP(hipStreamSynchronize(st));
 

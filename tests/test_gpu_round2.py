@@ -263,6 +263,44 @@ def test_ref_cpp_single_launch_equals_launch_list(api, ctx, orc, synth, small_wo
     assert icp.fused_count() == 6
 
 
+def test_large_sparse_extents_index_at_a_fine_cell(api, ctx, orc, synth):
+    """The dense cell table may take a quarter of the device's free memory: an explicit 0.25 m cell over a
+    1 km x 1 km x 100 m extent (6.4e9 cells, 64-bit cell ids, 25.6 GB of the 288 GB) and over 500 m x 500 m x 50 m
+    (8e8 cells: 32-bit ids, bounds by scan) index and answer exactly like the oracle kd-tree; a cell no device could
+    hold is still refused."""
+    rng = np.random.default_rng(12)
+    for extent, expect_wide in (((500.0, 500.0, 50.0), False), ((1000.0, 1000.0, 100.0), True)):
+        ext = np.array(extent)
+        corners = np.array([[0, 0, 0], [1, 1, 1], [1, 0, 1], [0.5, 0.5, 0.5], [0.03, 0.97, 0.2]]) * (ext - 20.0)
+        pts = np.concatenate([c + synth.make_map(60_000, seed=40 + k)[:40_000] % 20.0 for k, c in enumerate(corners)]).astype(np.float32)
+        pts = np.concatenate([pts, np.array([[0, 0, 0], ext], np.float32)])       # pin the bounding box
+        mp = api.Map(ctx, api.Cloud(ctx, pts), 0.25)
+        cell, dims = mp.cell_size()
+        ncell = int(dims[0]) * int(dims[1]) * int(dims[2])
+        assert abs(cell - 0.25) < 1e-7 and (ncell >= 2**32) == expect_wide and ncell > 2**28
+        q = np.concatenate([pts[rng.choice(len(pts), 4000)] + rng.normal(0, 0.05, (4000, 3)).astype(np.float32),       # near the clusters
+                            (rng.uniform(0, 1, (300, 3)) * ext).astype(np.float32)])                                   # in the void: many rings
+        oi, od = orc.KdTreeF(pts).nn(q)
+        gi, gd = mp.nn(q, 4.0)
+        hit = od < 4.0
+        assert np.array_equal(gi >= 0, hit) and np.array_equal(gd[hit], od[hit])
+        assert (gi[hit] != oi[hit]).mean() < 1e-3
+        scan = (pts[rng.choice(200_000, 3000, replace=False)].astype(np.float64) + rng.normal(0, 0.01, (3000, 3)))
+        T = synth.make_T((0.05, -0.03, 0.02), (0, 0, 0.5))
+        src = ((scan - T[:3, 3]) @ T[:3, :3]).astype(np.float32)
+        icp = api.Icp(ctx, 0.5, 30, 0.05, 1e-5)
+        icp.set_target(mp)
+        icp.set_source(src)
+        r = icp.align("o3d_p2p")
+        o = orc.icp_o3d_p2p(src, pts, np.eye(4), 0.5, 30)
+        assert r["iterations"] == o["iterations"] and r["n_corr"] == o["n_corr"]
+        dt, dr = synth.pose_error(r["T64"], o["T"])
+        assert dt < 1e-9 and dr < 1e-9
+        del mp, icp
+    with pytest.raises(api.SlamFusionError):
+        api.Map(ctx, api.Cloud(ctx, pts), 0.01)                                   # 1e15 cells
+
+
 def test_gpu_against_golden_extensions(api, ctx):
     from conftest import load_golden
     g, e = load_golden("registration_small.npz"), load_golden("extensions_small.npz")
