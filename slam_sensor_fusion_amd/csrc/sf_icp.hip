@@ -1106,7 +1106,7 @@ __global__ void k_set_int(int *__restrict__ p, int v) { *p = v; }
 __global__ void k_set_window(SfWindow *__restrict__ p, SfWindow w) { *p = w; }
 
 __global__ void k_ref_init(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n, const int *__restrict__ n_live,
-                           IcpState *__restrict__ st, float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz, int32_t *__restrict__ corr)
+                           IcpState *__restrict__ st, float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz, float4 *__restrict__ corr)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1122,18 +1122,20 @@ __global__ void k_ref_init(const float *__restrict__ X0x, const float *__restric
     Xx[o] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], x), __fmul_rn(T[1], y)), __fmul_rn(T[2], z)), T[3]);
     Xy[o] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], x), __fmul_rn(T[5], y)), __fmul_rn(T[6], z)), T[7]);
     Xz[o] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], x), __fmul_rn(T[9], y)), __fmul_rn(T[10], z)), T[11]);
-    corr[o] = 0; // alive
+    corr[o] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0)); // alive
 }
 
 // sourceTargetCorrespondences (icp_point_to_point.cpp:57-84): points without a match die
-// for good (corr = -1), the survivors remember the sorted position of their target.
+// for good (corr.w = -1), the survivors remember their target: its coordinates and its sorted position in one float4
+// record, so that the per-iteration record kernel streams 16 bytes per point instead of gathering them from the map
+// (measured at 32 scans in flight: k_ref_red 140-170 us as a gather).
 // The wave-cooperative search of sf_nn.hpp (every lane of a wave takes part, dead points and the tail included);
 // workgroups are placed like k_nn_red's: each XCD sweeps a contiguous eighth of the (cell-ordered) chunks for all scans
 // in flight.  grid.x is padded to a multiple of 8.
 template <bool WINDOW>
 __global__ __launch_bounds__(BLK) void k_ref_nn(SfGrid g, const SfWindow *__restrict__ wdev, const float *__restrict__ Xx, const float *__restrict__ Xy,
                                                 const float *__restrict__ Xz, int n, const int *__restrict__ n_live, const IcpState *__restrict__ st, float thr, int force,
-                                                int32_t *__restrict__ corr, int nblocks)
+                                                float4 *__restrict__ corr, int nblocks)
 {
     SfWindow w;
     if (WINDOW) w = *wdev; // the map crop lives in device memory: it moves with the pose, a captured launch list does not
@@ -1149,17 +1151,17 @@ __global__ __launch_bounds__(BLK) void k_ref_nn(SfGrid g, const SfWindow *__rest
     __shared__ sf::WaveNN nn_ws[BLK / 64];
     const int i = bx * BLK + threadIdx.x;
     const size_t o = (size_t)b * n + (size_t)(i < n ? i : 0);
-    const bool live = i < n && corr[o] >= 0;
+    const bool live = i < n && __float_as_int(corr[o].w) >= 0;
     const float qx = live ? Xx[o] : 0.0f, qy = live ? Xy[o] : 0.0f, qz = live ? Xz[o] : 0.0f;
     const sf::NNHit hit = sf::nn_search_wave<WINDOW, true>(g, w, live, qx, qy, qz, thr, &nn_ws[threadIdx.x >> 6]);
-    if (live) corr[o] = hit.j;
+    if (live) corr[o] = make_float4(hit.px, hit.py, hit.pz, __int_as_float(hit.j));
 }
 
 // optional in-place X <- step * X (float32, unfused), then the 17-scalar record over the
 // live pairs: n, sum s, sum t, sum s t^T, sum ||s - t|| (float32 norm, as
 // calculateErrorMetric icp_point_to_point.cpp:161-170 computes it per pair)
-__global__ __launch_bounds__(BLK) void k_ref_red(const float4 *__restrict__ pts, float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz, int n,
-                                                 const int *__restrict__ n_live, const IcpState *__restrict__ st, const int32_t *__restrict__ corr, int apply_step,
+__global__ __launch_bounds__(BLK) void k_ref_red(float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz, int n,
+                                                 const int *__restrict__ n_live, const IcpState *__restrict__ st, const float4 *__restrict__ corr, int apply_step,
                                                  int only_if_research, double *__restrict__ partials, int nblocks)
 {
     if (n_live) n = *n_live;
@@ -1176,8 +1178,8 @@ __global__ __launch_bounds__(BLK) void k_ref_red(const float4 *__restrict__ pts,
     for (int c = 0; c < NREC_P2P; ++c) acc[c] = 0.0;
     for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += nblocks * BLK) {
         const size_t o = (size_t)b * n + i;
-        const int j = corr[o];
-        if (j < 0) continue;
+        const float4 p = corr[o];
+        if (__float_as_int(p.w) < 0) continue;
         float x = Xx[o], y = Xy[o], z = Xz[o];
         if (do_step) {
             const float nx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], x), __fmul_rn(T[1], y)), __fmul_rn(T[2], z)), T[3]);
@@ -1186,7 +1188,6 @@ __global__ __launch_bounds__(BLK) void k_ref_red(const float4 *__restrict__ pts,
             x = nx; y = ny; z = nz;
             Xx[o] = x; Xy[o] = y; Xz[o] = z;
         }
-        const float4 p = pts[j];
         const float dx = x - p.x, dy = y - p.y, dz = z - p.z;
         const float nrm = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz))));
         const double sx = x, sy = y, sz = z, tx = p.x, ty = p.y, tz = p.z;
@@ -1447,7 +1448,7 @@ struct sf_icp {
     sf::DevBuf Xq, qkeys, qkeys2, qidx, qidx2; // cell-ordered copy of X0 and the sort's buffers
     int order = SF_ORDER_AUTO;
     bool ordered = false;    // this alignment reads Xq
-    sf::DevBuf corr;         // int32 [B*n] (REF_CPP)
+    sf::DevBuf corr;         // float4 [B*n] (REF_CPP): a point's target (x, y, z, sorted position or -1 = dead)
     int64_t n = 0;           // points per scan
     bool n_on_device = false; // sf_icp_set_source_scan: n is an upper bound, the count itself is in n_dev (single scan, REF_CPP)
     int64_t n_cap = 0;       // single scan: n rounded up (launch geometry of the REF_CPP kernels)
@@ -1781,9 +1782,9 @@ int enqueue_align(sf_icp *icp, int mode)
         }
     } else {
         SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(icp->plane, 1)));
-        SF_TRY(icp->corr.reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(icp->plane, 1)));
+        SF_TRY(icp->corr.reserve(sizeof(float4) * (size_t)std::max<int64_t>(icp->plane, 1)));
         float *Xx = soa(icp->X, icp->plane, 0), *Xy = soa(icp->X, icp->plane, 1), *Xz = soa(icp->X, icp->plane, 2);
-        int32_t *corr = icp->corr.as<int32_t>();
+        float4 *corr = icp->corr.as<float4>();
         const dim3 gpts((unsigned)icp->nblocks, (unsigned)B), gred((unsigned)icp->nblocks, (unsigned)B);
         const int *nl = B == 1 ? icp->n_dev.as<int>() : nullptr; // single scan: the count comes from the device (see k_ref_init)
         const bool win = m->window.kind != 0;
@@ -1795,7 +1796,7 @@ int enqueue_align(sf_icp *icp, int mode)
             else hipLaunchKernelGGL(k_ref_nn<false>, gnn, dim3(BLK), 0, s, m->grid, (const SfWindow *)nullptr, Xx, Xy, Xz, n, nl, st, thr, force, corr, icp->nblocks);
         };
         auto red = [&](int apply, int only_research) {
-            hipLaunchKernelGGL(k_ref_red, gred, dim3(BLK), 0, s, m->grid.pts, Xx, Xy, Xz, n, nl, st, corr, apply, only_research, part, icp->nblocks);
+            hipLaunchKernelGGL(k_ref_red, gred, dim3(BLK), 0, s, Xx, Xy, Xz, n, nl, st, corr, apply, only_research, part, icp->nblocks);
         };
         auto decide = [&](int phase) { hipLaunchKernelGGL(k_ref_decide, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks, icp->prm, phase); };
         hipLaunchKernelGGL(k_ref_init, gpts, dim3(BLK), 0, s, src(icp, 0), src(icp, 1), src(icp, 2), n, nl, st, Xx, Xy, Xz, corr); // the cell-ordered copy when ordering is on
@@ -2153,7 +2154,7 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     if (icp->use_graph && !icp->profiling && (icp->map->window.kind == 0 || mode == SF_ICP_REF_CPP)) {
         if (mode == SF_ICP_REF_CPP) { // buffers must exist before capture (and before the key is formed)
             SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(icp->plane, 1)));
-            SF_TRY(icp->corr.reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(icp->plane, 1)));
+            SF_TRY(icp->corr.reserve(sizeof(float4) * (size_t)std::max<int64_t>(icp->plane, 1)));
         }
         const sf_icp::GraphKey key = graph_key_now(icp, mode);
         const bool hit = icp->graph_exec && key == icp->graph_key;
