@@ -241,9 +241,10 @@ int sf_icp_use_graph(sf_icp *icp, int on); /* replay the launch sequence as a hi
  * cache key keeps changing).  REF_CPP with ONE scan reads the scan's point count and the map window from device memory,
  * so scans of similar size (same count rounded up to 4096) and a moving window replay the same graph. */
 int sf_icp_graph_counts(sf_icp *icp, int64_t *captures, int64_t *launches);
-/* REF_CPP alignments small enough for every workgroup to be resident at once (the node's per-scan path: ~13 k points)
- * run as ONE launch -- search, record, controller and step of icp_point_to_point.cpp:185-254 behind in-kernel grid
- * barriers, bit-identical to the launch list; on by default, larger alignments and profiled ones take the launch list.
+/* Alignments small enough for every workgroup to be resident at once (the nodes' per-scan paths: ~13 k points; up to
+ * 65 k points in REF_CPP, 131 k in the float64 modes, summed over the batch) run as ONE launch -- search, record,
+ * controller / solve and step behind in-kernel grid barriers (REF_CPP: icp_point_to_point.cpp:185-254), bit-identical to
+ * the launch list; on by default, larger alignments, sharded and profiled ones take the launch list.
  * sf_icp_fused_count: how many alignments have taken the single-launch form since creation. */
 int sf_icp_set_fused(sf_icp *icp, int on);
 int sf_icp_fused_count(sf_icp *icp, int64_t *launches);

@@ -479,6 +479,52 @@ struct LanePair {
     bool ok;
 };
 
+// Neighbour reuse with an exactness certificate.  The last full search of this query (at position
+// c0.xyz) found neighbour c1 = (point, index) and proved every OTHER map point at least c0.w
+// away.  The query has moved by delta since; if |q - p| < c0.w - delta (triangle inequality, with
+// a rounding margin) no other point can be nearer, so the search would return the same
+// neighbour -- it is skipped, the result is bit-identical.  ICP steps shrink geometrically, so
+// after the first few iterations whole waves certify (and then read their pair -- neighbour and
+// normal -- from three coalesced float4 streams instead of gathering it); a wave with any lane
+// left runs the search for just those lanes.
+// Returns whether the query must search; hit / tn = the certified pair (or "none yet"), seed = where a search may start.
+__device__ __forceinline__ bool reuse_certificate(bool valid, float qx, float qy, float qz, float thr, const float4 &c0, const float4 &c1, const float4 &c2, sf::NNHit &hit,
+                                                  float4 &tn, sf::NNHit &seed)
+{
+    hit.d2 = thr;
+    hit.j = -1;
+    hit.px = hit.py = hit.pz = 0.0f;
+    hit.lb2 = 0.0f;
+    tn = make_float4(0.f, 0.f, 0.f, 0.f); // the neighbour's normal (MODE 2)
+    bool need = valid;
+    seed = sf::NNHit{0.0f, -1, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (valid) {
+        if (c0.w > 0.0f) {
+            const int32_t jc = __float_as_int(c1.w);
+            const float dx = qx - c0.x, dy = qy - c0.y, dz = qz - c0.z;
+            const float reach = c0.w * 0.9999f - sqrtf(dx * dx + dy * dy + dz * dz) * 1.0001f - 1.0e-6f;
+            if (jc >= 0) {
+                const float d2n = sf::l2_simple(qx, qy, qz, c1.x, c1.y, c1.z);
+                if (sqrtf(d2n) * 1.0001f + 1.0e-6f < reach) {
+                    need = false;
+                    if (d2n < thr) {
+                        hit.d2 = d2n; hit.j = jc; hit.px = c1.x; hit.py = c1.y; hit.pz = c1.z;
+                        tn = c2;
+                    }
+                } else {
+                    // not certified: the search still starts from the old neighbour's current distance instead of the
+                    // acceptance threshold (exact all the same -- sf_nn.hpp -- and ranges beyond it are pruned unvisited;
+                    // measured: 2 % on the second to fourth launch of an alignment)
+                    seed.d2 = d2n; seed.j = jc; seed.px = c1.x; seed.py = c1.y; seed.pz = c1.z;
+                }
+            } else if (sqrtf(thr) * 1.0001f + 1.0e-6f < reach) {
+                need = false; // still nothing within the acceptance radius
+            }
+        }
+    }
+    return need;
+}
+
 template <int MODE, bool WINDOW, bool SHARD>
 __device__ __forceinline__ LanePair nn_pair(const SfGrid &g, const SfWindow &w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                             int n, int b, const IcpState *S, float thr, float xlo, float xhi, const uint32_t *__restrict__ own_off,
@@ -507,46 +553,10 @@ __device__ __forceinline__ LanePair nn_pair(const SfGrid &g, const SfWindow &w, 
         qx = (float)sx; qy = (float)sy; qz = (float)sz;
         valid = !SHARD || (qx >= xlo && qx < xhi);
     }
-    // Neighbour reuse with an exactness certificate.  The last full search of this query (at position
-    // c0.xyz) found neighbour c1 = (point, index) and proved every OTHER map point at least c0.w
-    // away.  The query has moved by delta since; if |q - p| < c0.w - delta (triangle inequality, with
-    // a rounding margin) no other point can be nearer, so the search would return the same
-    // neighbour -- it is skipped, the result is bit-identical.  ICP steps shrink geometrically, so
-    // after the first few iterations whole waves certify (and then read their pair -- neighbour and
-    // normal -- from three coalesced float4 streams instead of gathering it); a wave with any lane
-    // left runs the search for just those lanes.
     sf::NNHit hit;
-    hit.d2 = thr;
-    hit.j = -1;
-    hit.px = hit.py = hit.pz = 0.0f;
-    hit.lb2 = 0.0f;
-    float4 tn = make_float4(0.f, 0.f, 0.f, 0.f); // the neighbour's normal (MODE 2)
-    bool need = valid;
-    sf::NNHit seed{0.0f, -1, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (valid) {
-        if (c0.w > 0.0f) {
-            const int32_t jc = __float_as_int(c1.w);
-            const float dx = qx - c0.x, dy = qy - c0.y, dz = qz - c0.z;
-            const float reach = c0.w * 0.9999f - sqrtf(dx * dx + dy * dy + dz * dz) * 1.0001f - 1.0e-6f;
-            if (jc >= 0) {
-                const float d2n = sf::l2_simple(qx, qy, qz, c1.x, c1.y, c1.z);
-                if (sqrtf(d2n) * 1.0001f + 1.0e-6f < reach) {
-                    need = false;
-                    if (d2n < thr) {
-                        hit.d2 = d2n; hit.j = jc; hit.px = c1.x; hit.py = c1.y; hit.pz = c1.z;
-                        tn = c2;
-                    }
-                } else {
-                    // not certified: the search still starts from the old neighbour's current distance instead of the
-                    // acceptance threshold (exact all the same -- sf_nn.hpp -- and ranges beyond it are pruned unvisited;
-                    // measured: 2 % on the second to fourth launch of an alignment)
-                    seed.d2 = d2n; seed.j = jc; seed.px = c1.x; seed.py = c1.y; seed.pz = c1.z;
-                }
-            } else if (sqrtf(thr) * 1.0001f + 1.0e-6f < reach) {
-                need = false; // still nothing within the acceptance radius
-            }
-        }
-    }
+    float4 tn;
+    sf::NNHit seed;
+    const bool need = reuse_certificate(valid, qx, qy, qz, thr, c0, c1, c2, hit, tn, seed);
     // every lane takes part in the search (lanes without a query still execute other lanes' tasks)
     const unsigned long long need_mask = __ballot(need);
     if (stats && (threadIdx.x & 63) == 0 && need_mask) { // profiling only (integer counters: order independent); sharded: one address would serialise 100 k waves
@@ -1432,6 +1442,118 @@ __global__ __launch_bounds__(BLK) void k_ref_fused(SfGrid g, SfWindow w, const f
     }
 }
 
+// ------------------------------------------------------------------ O3D_P2P / P2PLANE, the whole alignment in ONE launch
+// The same single-launch form for the float64 modes (the Python node's registration_icp call, the mapping flow, small
+// batches): per iteration the body of k_nn_red -- with the lane's neighbour cache (position of its last search, runner-up
+// bound, neighbour, normal) kept in REGISTERS instead of three float4 streams -- the slab row, one grid barrier, the
+// fixed-order slab sum and the solve of k_reduce_solve evaluated by every workgroup on its LDS copy of the state.
+// Bit-identical to the launch list (same rows, same sums, same certificate; tests/test_gpu_round2.py).
+template <int MODE, bool WINDOW, bool REUSE>
+__global__ __launch_bounds__(BLK) void k_icp_fused(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
+                                                   IcpState *__restrict__ st, float thr, int K, double *__restrict__ partials, int nblocks, uint32_t *__restrict__ bar)
+{
+    constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
+    const int b = blockIdx.y, bx = blockIdx.x;
+    __shared__ IcpState S;
+    __shared__ double rec[REC_STRIDE];
+    __shared__ sf::WaveNN nn_ws[BLK / 64];
+    __shared__ double stage[BLK / 64][32];
+    __shared__ int bar_ok;
+    for (int k = threadIdx.x; k < (int)(sizeof(IcpState) / 4); k += BLK) reinterpret_cast<uint32_t *>(&S)[k] = reinterpret_cast<const uint32_t *>(st + b)[k];
+    __syncthreads();
+    uint32_t *ctr = bar + 2 * b, *fin = bar + 2 * b + 1;
+    double *slab = partials + (size_t)b * nblocks * REC_STRIDE;
+    const int slot = bx * BLK + (int)threadIdx.x;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool have = slot < n;
+    double x0 = 0.0, y0 = 0.0, z0 = 0.0;
+    if (have) {
+        const size_t o = (size_t)b * n + (size_t)slot;
+        x0 = X0x[o]; y0 = X0y[o]; z0 = X0z[o];
+    }
+    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0; // the lane's neighbour cache (k_nn_red keeps it in memory)
+    uint32_t passed = 0;
+    bool alive = true;
+    const int launches = MODE == 1 ? K + 1 : K; // what the launch list enqueues
+    for (int it = 0; it < launches && !S.done; ++it) {
+        double sx = 0, sy = 0, sz = 0;
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if (have) {
+            sx = S.T[0] * x0 + S.T[1] * y0 + S.T[2] * z0 + S.T[3];
+            sy = S.T[4] * x0 + S.T[5] * y0 + S.T[6] * z0 + S.T[7];
+            sz = S.T[8] * x0 + S.T[9] * y0 + S.T[10] * z0 + S.T[11];
+            qx = (float)sx; qy = (float)sy; qz = (float)sz;
+        }
+        sf::NNHit hit;
+        float4 tn;
+        sf::NNHit seed;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool live = REUSE && S.n_research > 0;
+        const bool need = reuse_certificate(have, qx, qy, qz, thr, live ? c0 : z4, live ? c1 : z4, live ? c2 : z4, hit, tn, seed);
+        if (__ballot(need) != 0ull) {
+            const sf::NNHit h = sf::nn_search_wave<WINDOW>(g, w, need, qx, qy, qz, thr, &nn_ws[wv], seed);
+            if (need) {
+                hit = h;
+                if (MODE == 2 && h.j >= 0) tn = g.nrm[h.j];
+                if (REUSE) {
+                    c0 = make_float4(qx, qy, qz, sqrtf(h.lb2));
+                    c1 = make_float4(h.px, h.py, h.pz, __int_as_float(h.j));
+                    c2 = tn;
+                }
+            }
+        }
+        LanePair P;
+        P.sx = sx; P.sy = sy; P.sz = sz;
+        P.px = hit.px; P.py = hit.py; P.pz = hit.pz;
+        P.tn = tn;
+        P.ok = hit.j >= 0;
+        const PairTerms T = pair_terms<MODE>(P);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = 0.0;
+            add_half<MODE>(T, h, v);
+            if (MODE == 1 && h == 1) {
+                const double t1 = wave_reduce_1(v[0]);
+                if (lane == 0) stage[wv][16] = t1;
+            } else {
+                const double t0 = wave_reduce_16(v);
+                if ((lane & 3) == 0) stage[wv][16 * h + (lane >> 2)] = t0;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < NREC) {
+            const int c = threadIdx.x;
+            slab[(size_t)bx * REC_STRIDE + c] = ((stage[0][c] + stage[1][c]) + stage[2][c]) + stage[3][c];
+        }
+        ++passed;
+        alive = ref_grid_barrier(ctr, passed * (uint32_t)nblocks, &bar_ok);
+        if (!alive) break;
+        reduce_partials<NREC, BLK>(slab, nblocks, rec);
+        if (threadIdx.x == 0) {
+            for (int c = 0; c < NREC; ++c) S.rec[c] = rec[c];
+            if (MODE == 1) solve_o3d(&S, rec, n, 0, K);
+            else solve_plane(&S, rec, n, K);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (!alive) {
+        if (threadIdx.x == 0) atomicOr(&st[b].flags, SF_ICP_FLAG_BARRIER_TIMEOUT);
+        return;
+    }
+    if (bx == 0)
+        for (int k = threadIdx.x; k < (int)(sizeof(IcpState) / 4); k += BLK) reinterpret_cast<uint32_t *>(st + b)[k] = reinterpret_cast<const uint32_t *>(&S)[k];
+    if (threadIdx.x == 0) {
+        const uint32_t left = __hip_atomic_fetch_add(fin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == (uint32_t)nblocks - 1u) {
+            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 } // namespace
 
 // ==================================================================== host side
@@ -1489,7 +1611,7 @@ struct sf_icp {
     bool fused = true;       // sf_icp_set_fused
     bool last_fused = false; // the last alignment ran as the single launch
     sf::DevBuf bar;          // per scan: {arrival counter, departure counter} of the grid barrier
-    int fused_limit = -1;    // workgroups that are certainly resident together (-1: not asked yet)
+    int fused_limit[3] = {-1, -1, -1}; // per mode: workgroups that are certainly resident together (-1: not asked yet)
     int64_t fused_launches = 0;
     // graph
     bool use_graph = false;
@@ -1818,26 +1940,58 @@ int enqueue_align(sf_icp *icp, int mode)
 // The single-launch form needs every workgroup of the grid resident at once (its grid barrier waits for all of them).
 // The occupancy query can read one workgroup per CU high on this part (MI355X_MICROARCH.md, residency), so one is
 // taken off and the rest capped at 4 per CU; larger alignments take the launch list.
-int fused_capacity(sf_icp *icp)
+template <class... KERNELS>
+int resident_workgroups(sf_icp *icp, KERNELS... kernels)
 {
-    if (icp->fused_limit >= 0) return icp->fused_limit;
-    int per_cu_w = 0, per_cu = 0;
-    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, k_ref_fused<true>, BLK, 0);
-    hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ref_fused<false>, BLK, 0);
+    int per_cu = 1 << 20;
+    bool ok = true;
+    auto ask = [&](auto kernel) {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, BLK, 0) != hipSuccess) ok = false;
+        per_cu = std::min(per_cu, v);
+    };
+    (ask(kernels), ...);
     hipDeviceProp_t prop;
-    hipError_t e3 = hipGetDeviceProperties(&prop, icp->ctx->device);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { icp->fused_limit = 0; return 0; }
-    const int k = std::min(std::min(per_cu_w, per_cu) - 1, 4);
-    icp->fused_limit = std::max(k, 0) * prop.multiProcessorCount;
-    return icp->fused_limit;
+    if (!ok || hipGetDeviceProperties(&prop, icp->ctx->device) != hipSuccess) return 0;
+    return std::max(std::min(per_cu - 1, 4), 0) * prop.multiProcessorCount;
+}
+
+int fused_capacity(sf_icp *icp, int mode)
+{
+    int &slot = icp->fused_limit[mode];
+    if (slot >= 0) return slot;
+    if (mode == SF_ICP_REF_CPP) slot = resident_workgroups(icp, k_ref_fused<true>, k_ref_fused<false>);
+    else if (mode == SF_ICP_O3D_P2P)
+        slot = resident_workgroups(icp, k_icp_fused<1, true, true>, k_icp_fused<1, false, true>, k_icp_fused<1, true, false>, k_icp_fused<1, false, false>);
+    else
+        slot = resident_workgroups(icp, k_icp_fused<2, true, true>, k_icp_fused<2, false, true>, k_icp_fused<2, true, false>, k_icp_fused<2, false, false>);
+    return slot;
 }
 
 bool fused_eligible(sf_icp *icp, int mode)
 {
-    return mode == SF_ICP_REF_CPP && icp->fused && !icp->profiling && !icp->shard && (int64_t)icp->nblocks * icp->batch <= (int64_t)fused_capacity(icp);
+    const int64_t rows = mode == SF_ICP_REF_CPP ? icp->nblocks : icp->nblocks_nn;
+    return icp->fused && !icp->profiling && !icp->shard && rows * icp->batch <= (int64_t)fused_capacity(icp, mode);
 }
 
-int launch_fused(sf_icp *icp)
+template <int MODE>
+void launch_icp_fused(sf_icp *icp, dim3 grid)
+{
+    sf_map *m = icp->map;
+    hipStream_t s = icp->ctx->stream;
+    const float thr = o3d_thr(icp);
+    const bool win = m->window.kind != 0;
+#define SF_LAUNCH_ICPF(W, R)                                                                                                                                               \
+    hipLaunchKernelGGL((k_icp_fused<MODE, W, R>), grid, dim3(BLK), 0, s, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n, icp->state.as<IcpState>(), thr, \
+                       icp->prm.num_iters, icp->partials.as<double>(), icp->nblocks_nn, icp->bar.as<uint32_t>())
+    if (win && icp->reuse) SF_LAUNCH_ICPF(true, true);
+    else if (win) SF_LAUNCH_ICPF(true, false);
+    else if (icp->reuse) SF_LAUNCH_ICPF(false, true);
+    else SF_LAUNCH_ICPF(false, false);
+#undef SF_LAUNCH_ICPF
+}
+
+int launch_fused(sf_icp *icp, int mode)
 {
     sf_map *m = icp->map;
     hipStream_t s = icp->ctx->stream;
@@ -1846,6 +2000,14 @@ int launch_fused(sf_icp *icp)
     if (icp->bar.cap < need) {
         SF_TRY(icp->bar.reserve(need));
         SF_HIP(hipMemsetAsync(icp->bar.p, 0, icp->bar.cap, s)); // afterwards the kernel leaves the counters at zero itself
+    }
+    if (mode != SF_ICP_REF_CPP) {
+        const dim3 grid_nn((unsigned)icp->nblocks_nn, (unsigned)B);
+        if (mode == SF_ICP_O3D_P2P) launch_icp_fused<1>(icp, grid_nn);
+        else launch_icp_fused<2>(icp, grid_nn);
+        SF_HIP(hipGetLastError());
+        icp->fused_launches += 1;
+        return SF_OK;
     }
     const dim3 grid((unsigned)icp->nblocks, (unsigned)B);
     const float thr = icp->prm.max_corr; // squared-vs-unsquared quirk, icp_point_to_point.cpp:70
@@ -1872,8 +2034,8 @@ int check_barrier_flags(sf_icp *icp)
     if (!bad) return SF_OK;
     hipError_t e = hipMemsetAsync(icp->bar.p, 0, icp->bar.cap, icp->ctx->stream);
     (void)e;
-    icp->fused_limit = 0; // no second attempt on this object
-    sf::set_error("REF_CPP single-launch alignment: a grid barrier timed out (results invalid); the launch list is used from now on");
+    for (int &v : icp->fused_limit) v = 0; // no second attempt on this object
+    sf::set_error("single-launch alignment: a grid barrier timed out (results invalid); the launch list is used from now on");
     return SF_ERR_HIP;
 }
 
@@ -2140,9 +2302,9 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     icp->last_mode = mode;
     SF_TRY(launch_state_init(icp));
     icp->last_fused = fused_eligible(icp, mode);
-    if (icp->last_fused) { // REF_CPP, everything resident at once: the whole alignment is one launch (window and count by value)
+    if (icp->last_fused) { // everything resident at once: the whole alignment is one launch (window and count by value)
         SF_TRY(order_queries(icp, mode));
-        return launch_fused(icp);
+        return launch_fused(icp, mode);
     }
     if (mode == SF_ICP_REF_CPP && icp->map->window.kind != 0) { // the map crop as it stands now, for the kernels that read it from the device
         SF_TRY(icp->map->d_window.reserve(sizeof(SfWindow)));

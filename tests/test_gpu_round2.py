@@ -263,6 +263,53 @@ def test_ref_cpp_single_launch_equals_launch_list(api, ctx, orc, synth, small_wo
     assert icp.fused_count() == 6
 
 
+def test_o3d_and_p2plane_single_launch_equals_launch_list(api, ctx, orc, synth, small_world):
+    """The float64 modes as ONE launch (k_icp_fused: the neighbour cache in registers, grid barriers, the solve evaluated
+    by every workgroup): bit-identical to the launch list -- with and without neighbour reuse, with a sphere / box window,
+    for a batch in which one scan has nothing within reach, for a single scan of odd size -- and equal to the oracle."""
+    m = small_world["map"]
+    mp = api.Map(ctx, api.Cloud(ctx, m), 0.25)
+    mp.estimate_normals(0.25)
+    normals, _ = mp.download_normals()
+    keys = ("iterations", "converged", "n_corr", "n_research", "flags", "rmse", "fitness")
+    scans = np.stack([synth.make_scan(m, 7000, scan_id=60 + k)[0] for k in range(3)])
+    scans[2] += np.float32(400.0)
+    inits = np.stack([synth.make_T((0.02 * k, -0.01, 0.0), (0, 0.02, 0.1 * k)) for k in range(3)])
+    for mode, iters in (("o3d_p2p", 30), ("p2plane", 12), ("o3d_p2p", 0)):
+        for window in (None, "sphere", "box"):
+            if window == "sphere":
+                mp.window_sphere(np.array([0.2, -0.1, 0.0], np.float32), 4.5)
+            elif window == "box":
+                mp.window_obb(np.array([0.1, 0.2, 0.0]), synth.make_T((0, 0, 0), (0, 0, 20.0))[:3, :3], np.array([4.0, 3.5, 2.0]))
+            else:
+                mp.window_none()
+            out = []
+            for fused, reuse in ((True, True), (False, True), (True, False), (False, False)):
+                icp = api.Icp(ctx, 0.5, iters, 0.05, 1e-5)
+                icp.set_fused(fused)
+                icp.set_nn_reuse(reuse)
+                icp.set_target(mp)
+                icp.set_source_batch(scans)
+                icp.set_initial_batch(inits)
+                r = icp.align_batch(mode)
+                assert icp.fused_count() == (1 if fused else 0)
+                icp.set_source(scans[1][:4321])
+                icp.set_initial_transformation(inits[1])
+                r.append(icp.align(mode))
+                assert icp.fused_count() == (2 if fused else 0)
+                out.append(r)
+            for other in out[1:]:
+                for a, b in zip(out[0], other):
+                    assert np.array_equal(a["T64"], b["T64"]) and all(a[k] == b[k] for k in keys), (mode, window)
+            assert out[0][2]["n_corr"] == 0
+            if window is None and iters > 0:
+                src = scans[1][:4321]
+                o = orc.icp_o3d_p2p(src, m, inits[1], 0.5, iters) if mode == "o3d_p2p" else orc.icp_p2plane(src, m, normals, inits[1], 0.5, iters)
+                dt, dr = synth.pose_error(out[0][3]["T64"], o["T"])
+                assert out[0][3]["iterations"] == o["iterations"] and dt < 1e-9 and dr < 1e-9
+    mp.window_none()
+
+
 def test_large_sparse_extents_index_at_a_fine_cell(api, ctx, orc, synth):
     """The dense cell table may take a quarter of the device's free memory: an explicit 0.25 m cell over a
     1 km x 1 km x 100 m extent (6.4e9 cells, 64-bit cell ids, 25.6 GB of the 288 GB) and over 500 m x 500 m x 50 m

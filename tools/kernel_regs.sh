@@ -11,7 +11,7 @@ for l in sys.stdin:
     for key in ('VGPRs', 'Occupancy \[waves/SIMD\]', 'SGPRs Spill', 'ScratchSize \[bytes/lane\]', 'LDS Size \[bytes/block\]'):
         m = re.search(key + r': (\d+)', l)
         if m and name: d[key] = m.group(1)
-    if name and 'LDS Size' in l and any(k in name for k in ('k_nn_red', 'k_ref_nn', 'k_ref_fused', 'k_bf', 'k_map_nn')):
+    if name and 'LDS Size' in l and any(k in name for k in ('k_nn_red', 'k_ref_nn', 'k_ref_fused', 'k_bf', 'k_map_nn', 'k_icp_fused')):
         short = re.sub(r'^_ZN12_GLOBAL__N_1\d+', '', name)[:28]
         print(short, 'vgpr', d.get('VGPRs'), 'occ', d.get('Occupancy \[waves/SIMD\]'), 'sgpr-spill', d.get('SGPRs Spill'), 'scratch', d.get('ScratchSize \[bytes/lane\]'), 'lds', d.get('LDS Size \[bytes/block\]'))
 "
