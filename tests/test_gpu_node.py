@@ -164,6 +164,57 @@ def test_source_scan_one_pass_equals_separate_operations(api, ctx, orc, synth, s
             assert res[0]["flags"] & api.SF_ICP_FLAG_FEW_CORR and res[0]["iterations"] == 0
 
 
+def test_cpp_node_class_equals_native_flow(tmp_path, api, ctx, orc, synth):
+    """include/localization/localization_node.h (LocalizationCore over sf_node_*) compiled with g++ against the C ABI
+    and driven from files: the poses it prints equal the ones the Python wrapper of the same entry points gets."""
+    import os
+    import struct
+    import subprocess
+    from conftest import ROOT
+    from slam_sensor_fusion_amd.localization_flow import NativeLocalizationFlow
+    exe = str(tmp_path / "test_node_class")
+    libdir = os.path.join(ROOT, "slam_sensor_fusion_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_node_class.cpp"), "-o", exe,
+                           "-L" + libdir, "-lslamfusion", "-Wl,-rpath," + libdir])
+    raw = synth.make_map(400_000, seed=31)
+    ds = orc.voxel_pcl(raw, 0.1)[0]
+    ds.tofile(tmp_path / "map.bin")
+    lla0 = np.array([[-22.9068, -43.1729, 12.0]])
+    mtg = api.map_T_global(lla0, np.zeros(1, np.float32))
+    flow = NativeLocalizationFlow(ctx, ds, mtg, altitude_table=lla0)
+    flow.coarse_alignment_complete_ = True
+    gps_cov, odom_cov = np.diag([0.25, 0.25, 0.25]).ravel(), np.diag([1e-4] * 6).ravel()
+    rng = np.random.default_rng(5)
+    expect, n_msg = [], 8
+    with open(tmp_path / "messages.bin", "wb") as f:
+        prev_truth = None
+        for k in range(n_msg):
+            truth = synth.make_T((0.45 * k - 1.5, 0.05 * k, 0.0), (0, 0, 1.0 * k))
+            scan = make_sensor_scan(synth, ds, truth, 8000, 300 + k)
+            gps, odom = messages_for(truth, k, rng, gps_cov, odom_cov)
+            start = np.zeros(16, np.float32)
+            if k == 1:
+                start = prev_truth.astype(np.float32).ravel()
+                flow.map_T_sensor_ = prev_truth.astype(np.float32)
+                flow.map_T_ref_ = prev_truth.astype(np.float32)
+            f.write(struct.pack("<qd", len(scan), 90.0 - k))
+            f.write(np.concatenate([[gps["latitude"], gps["longitude"], gps["altitude"]], gps["position_covariance"]]).astype(np.float64).tobytes())
+            f.write(np.concatenate([odom["q_wxyz"], odom["t"], odom["covariance"]]).astype(np.float64).tobytes())
+            f.write(start.tobytes())
+            f.write(scan.tobytes())
+            flow.compassCallback(90.0 - k)
+            out = flow.localizationCallback(scan, gps, odom)
+            expect.append((out is not None, flow.out_.icp.iterations if out is not None else 0, int(flow.out_.n_scan), np.array(flow.out_.map_T_sensor, np.float32)))
+            prev_truth = truth
+    lines = subprocess.check_output([exe, str(tmp_path / "map.bin"), str(tmp_path / "messages.bin"), str(n_msg)]).decode().strip().splitlines()
+    assert len(lines) == n_msg
+    for (ok, iters, n_scan, T), line in zip(expect, lines):
+        v = line.split()
+        assert int(v[0]) == int(ok) and int(v[1]) == iters and int(v[2]) == n_scan
+        assert np.array_equal(np.array([float(x) for x in v[3:19]], np.float32), T)
+    assert sum(e[0] for e in expect) == n_msg - 1
+
+
 def api_o3d(api, ctx, mp, cloud, init):
     icp = api.Icp(ctx, 0.5, 10, 0.001, 1e-5)
     icp.set_target(mp)
