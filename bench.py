@@ -169,7 +169,25 @@ def main():
             dist.broadcast_object_list(ident, src=lo, group=groups[(lo, hi)] if (lo, hi) in groups else None)
             if ident[0] is None:
                 raise RuntimeError("no RCCL unique id for ranks %d..%d" % (lo, hi))
-            return api.Comm(ctx, hi - lo + 1, rank - lo, ident[0])
+            # ncclCommInitRank blocks until every member has called it; should it never return (a rank lost, a bootstrap
+            # interface that cannot be reached) the bench must still finish: the call runs in a worker with a time limit and
+            # every rank then takes the torch.distributed path (the flag all-reduce below makes that decision common)
+            import threading
+            box = {}
+
+            def work():
+                try:
+                    box["comm"] = api.Comm(ctx, hi - lo + 1, rank - lo, ident[0])
+                except Exception as e:             # noqa: BLE001
+                    box["err"] = e
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("SF_COMM_INIT_TIMEOUT_S", "180")))
+            if th.is_alive():
+                raise RuntimeError("RCCL communicator of ranks %d..%d did not come up in time" % (lo, hi))
+            if "err" in box:
+                raise box["err"]
+            return box["comm"]
 
         groups = {}
         if args.scan_kind == "local" and world > 1:   # torch sub-groups: rendezvous for the ids (and the torch fallback's collectives)
