@@ -470,6 +470,9 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
 // added and go through ONE wave reduction.  Measured: QPL = 2 (half the reductions and slab rows,
 // 87 instead of 80 VGPR) is within 1 % of QPL = 1 at 1, 8 and 32 scans in flight -- the simpler one stays.
 constexpr int QPL = 1;
+#ifndef NN_RED_WAVES
+#define NN_RED_WAVES 4
+#endif
 constexpr int NN_STATS_SHARDS = 256; // counters of one profiled launch
 
 struct LanePair {
@@ -648,7 +651,7 @@ __device__ __forceinline__ void add_half(const PairTerms &t, int h, double (&v)[
 }
 
 template <int MODE, bool WINDOW, bool SHARD>
-__global__ __launch_bounds__(BLK, 4) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
+__global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                                 int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks,
                                                 const uint32_t *__restrict__ own_off, float4 *__restrict__ qcache, int64_t cache_n, uint32_t *__restrict__ stats)
 {
