@@ -310,6 +310,49 @@ def test_o3d_and_p2plane_single_launch_equals_launch_list(api, ctx, orc, synth, 
     mp.window_none()
 
 
+def test_single_launch_fuzz_against_launch_list(api, ctx, synth, small_world):
+    """Seeded fuzz of the single-launch alignments (all three modes) against their launch lists: random scan sizes
+    (1 .. 40 k points, batches of 1-3), iteration counts, thresholds, windows, start poses near and far -- every result
+    must be bit-identical.  Exercises the grid barriers and the cross-workgroup visibility of the slab rows under varying
+    grid sizes; SF_FUZZ_TRIALS / SF_FUZZ_SEED override the defaults."""
+    import os
+    m = small_world["map"]
+    mp = api.Map(ctx, api.Cloud(ctx, m), 0.25)
+    mp.estimate_normals(0.25)
+    rng = np.random.default_rng(int(os.environ.get("SF_FUZZ_SEED", "2024")))
+    keys = ("iterations", "converged", "n_corr", "n_research", "flags", "error", "rmse", "fitness")
+    trials = int(os.environ.get("SF_FUZZ_TRIALS", "40"))
+    pool = np.concatenate([synth.make_scan(m, 30000, scan_id=500 + k)[0] for k in range(2)])
+    for t in range(trials):
+        mode = ("ref_cpp", "o3d_p2p", "p2plane")[t % 3]
+        B = int(rng.integers(1, 4))
+        n = int(rng.choice([1, 9, 63, 64, 65, 255, 256, 257, 1000, 4097, int(rng.integers(2, 40000 // B))]))
+        scans = np.stack([pool[rng.choice(len(pool), n, replace=False)] for _ in range(B)])
+        if rng.random() < 0.3:
+            scans[rng.integers(0, B)] += np.float32(rng.choice([0.3, 3.0, 300.0]))
+        inits = np.stack([synth.make_T(rng.normal(0, 0.03, 3), rng.normal(0, 0.3, 3)) for _ in range(B)])
+        kind = rng.integers(0, 3)
+        if kind == 1:
+            mp.window_sphere(rng.normal(0, 0.5, 3).astype(np.float32), float(rng.uniform(1.0, 6.0)))
+        elif kind == 2:
+            mp.window_obb(rng.normal(0, 0.5, 3), synth.make_T((0, 0, 0), rng.normal(0, 20, 3))[:3, :3], rng.uniform(1.0, 5.0, 3))
+        else:
+            mp.window_none()
+        prm = (float(rng.choice([0.1, 0.5, 5.0])), int(rng.integers(0, 25)), float(rng.choice([0.001, 0.05, 0.4])), float(rng.choice([1e-5, 5e-3])))
+        out = []
+        for fused in (True, False):
+            icp = api.Icp(ctx, *prm)
+            icp.set_fused(fused)
+            icp.set_target(mp)
+            icp.set_source_batch(scans)
+            icp.set_initial_batch(inits)
+            out.append(icp.align_batch(mode))
+            assert icp.fused_count() == int(fused)
+        for a, b in zip(*out):
+            assert np.array_equal(a["T64"], b["T64"]) and all(a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]) for k in keys), (t, mode, B, n, prm, kind)
+    mp.window_none()
+
+
 def test_large_sparse_extents_index_at_a_fine_cell(api, ctx, orc, synth):
     """The dense cell table may take a quarter of the device's free memory: an explicit 0.25 m cell over a
     1 km x 1 km x 100 m extent (6.4e9 cells, 64-bit cell ids, 25.6 GB of the 288 GB) and over 500 m x 500 m x 50 m
