@@ -1164,9 +1164,14 @@ __global__ __launch_bounds__(BLK) void k_ref_nn(SfGrid g, const SfWindow *__rest
     __shared__ sf::WaveNN nn_ws[BLK / 64];
     const int i = bx * BLK + threadIdx.x;
     const size_t o = (size_t)b * n + (size_t)(i < n ? i : 0);
-    const bool live = i < n && __float_as_int(corr[o].w) >= 0;
+    const float4 old = i < n ? corr[o] : make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+    const bool live = __float_as_int(old.w) >= 0;
     const float qx = live ? Xx[o] : 0.0f, qy = live ? Xy[o] : 0.0f, qz = live ? Xz[o] : 0.0f;
-    const sf::NNHit hit = sf::nn_search_wave<WINDOW, true>(g, w, live, qx, qy, qz, thr, &nn_ws[threadIdx.x >> 6]);
+    // a re-search (cpp:221-224: the error has stalled, the points have hardly moved) starts from the target the point
+    // already has: exact all the same (sf_nn.hpp, seed), and almost every neighbour range is pruned unvisited
+    sf::NNHit seed{0.0f, -1, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (live && !force) { seed.d2 = sf::l2_simple(qx, qy, qz, old.x, old.y, old.z); seed.j = __float_as_int(old.w); seed.px = old.x; seed.py = old.y; seed.pz = old.z; }
+    const sf::NNHit hit = sf::nn_search_wave<WINDOW, true>(g, w, live, qx, qy, qz, thr, &nn_ws[threadIdx.x >> 6], seed);
     if (live) corr[o] = make_float4(hit.px, hit.py, hit.pz, __int_as_float(hit.j));
 }
 
@@ -1364,9 +1369,11 @@ __global__ __launch_bounds__(BLK) void k_ref_fused(SfGrid g, SfWindow w, const f
 #endif
     FTRACE(0);
     // sourceTargetCorrespondences (k_ref_nn): points without a match die for good
-    auto search = [&]() {
+    auto search = [&](bool first) {
         const bool live = corr >= 0;
-        const sf::NNHit hit = sf::nn_search_wave<WINDOW, true>(g, w, live, x, y, z, thr, &nn_ws[threadIdx.x >> 6]);
+        sf::NNHit seed{0.0f, -1, 0.0f, 0.0f, 0.0f, 0.0f}; // a re-search starts from the target the point already has (k_ref_nn)
+        if (live && !first) { seed.d2 = sf::l2_simple(x, y, z, tx, ty, tz); seed.j = corr; seed.px = tx; seed.py = ty; seed.pz = tz; }
+        const sf::NNHit hit = sf::nn_search_wave<WINDOW, true>(g, w, live, x, y, z, thr, &nn_ws[threadIdx.x >> 6], seed);
         if (live) { corr = hit.j; tx = hit.px; ty = hit.py; tz = hit.pz; }
         __syncthreads();
         FTRACE(1);
@@ -1409,14 +1416,14 @@ __global__ __launch_bounds__(BLK) void k_ref_fused(SfGrid g, SfWindow w, const f
     };
     const int K = prm.num_iters;
     if (!S.done) {
-        search();
+        search(true);
         record(false);
         if (alive) decide(0);
         for (int it = 0; alive && it < K && !S.done; ++it) {
             decide(1);
             if (S.done) break;
             if (S.research) {
-                search();
+                search(false);
                 record(false);
                 if (!alive) break;
                 decide(2);
