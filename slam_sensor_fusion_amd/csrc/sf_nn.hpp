@@ -110,7 +110,10 @@ __device__ __forceinline__ void consider(const SfWindow &w, float px, float py, 
 {
     const float d2 = l2_simple(qx, qy, qz, px, py, pz);
     const bool take = valid && hit_key(d2, j) < hit_key(hit.d2, hit.j) && (!WINDOW || window_accepts(w, px, py, pz));
-    if (TRACK && valid && j != hit.j) hit.lb2 = fminf(hit.lb2, take ? hit.d2 : d2);
+    // runner-up bound: hit.d2 <= hit.lb2 holds while ranges are scanned, so the median of (this candidate, the best, the
+    // bound) IS min(bound, the loser of this comparison) -- one v_med3_f32; the best itself met again and slots without a
+    // candidate enter as +big and leave the bound alone
+    if (TRACK) hit.lb2 = __builtin_amdgcn_fmed3f((valid && j != hit.j) ? d2 : 3.0e38f, hit.d2, hit.lb2);
     if (take) {
         hit.d2 = d2;
         hit.j = j;
@@ -343,6 +346,8 @@ struct WaveNN {
     uint32_t lb2[64];            // float bits: lower bound of the squared distance to every point but the best
     float4 q[64];
     RowBounds rb0[64];           // bounds of the own cell and its x neighbours (tasks 0, 1, 10)
+    float gap[6][64];            // the owner's gaps (gxm2, gxp2, gym, gyp, gzm, gzp) and ...
+    unsigned long long cell0[64]; // ... the linear index of its cell: a task gets its geometry from here instead of recomputing it (~45 instructions per task)
     uint16_t task[64 * 11];      // owner lane << 4 | t, grouped by t
 };
 
@@ -445,6 +450,11 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
                 else hit.lb2 = fminf(hit.lb2, gap2);
             }
         }
+        if (mask) { // what the tasks of this query need of its geometry
+            ws->gap[0][lane] = G.gxm2; ws->gap[1][lane] = G.gxp2;
+            ws->gap[2][lane] = G.gym; ws->gap[3][lane] = G.gyp; ws->gap[4][lane] = G.gzm; ws->gap[5][lane] = G.gzp;
+            ws->cell0[lane] = ((unsigned long long)G.cz * (unsigned long long)ny + (unsigned long long)G.cy) * (unsigned long long)nx + (unsigned long long)G.cx;
+        }
     }
     ws->best[lane] = pack_hit(hit.d2, hit.j);
     ws->lb2[lane] = __float_as_uint(hit.lb2);
@@ -466,7 +476,10 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
             const uint32_t e = ws->task[idx];
             const int owner = (int)(e >> 4), t = (int)(e & 15u);
             const float4 Q = ws->q[owner];
-            const QueryGeo G = query_geo(g, Q.x, Q.y, Q.z);
+            QueryGeo G; // from the owner's entry (cx, cy, cz are not needed: the row is addressed relative to the owner's cell)
+            G.cx = G.cy = G.cz = 0;
+            G.gxm2 = ws->gap[0][owner]; G.gxp2 = ws->gap[1][owner];
+            G.gym = ws->gap[2][owner]; G.gyp = ws->gap[3][owner]; G.gzm = ws->gap[4][owner]; G.gzp = ws->gap[5][owner];
             const unsigned long long start = __atomic_load_n(&ws->best[owner], __ATOMIC_RELAXED);
             const float cur = __uint_as_float((uint32_t)(start >> 32));
             const bool own_row = t < 2 || t == 10;
@@ -480,7 +493,8 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
                     a = t == 0 ? rb.s0 : (t == 1 ? rb.s2 : rb.s1 + 4);
                     b = t == 0 ? rb.s1 : (t == 1 ? rb.s3 : rb.s2);
                 } else {
-                    const RowBounds rb = load_row_bounds(g, ((size_t)(G.cz + row_dz(t - 2)) * ny + (G.cy + row_dy(t - 2))) * nx + G.cx);
+                    const long long step = ((long long)row_dz(t - 2) * ny + row_dy(t - 2)) * nx; // the row's cell relative to the owner's (inside the grid: checked when queued)
+                    const RowBounds rb = load_row_bounds(g, (size_t)((long long)ws->cell0[owner] + step));
                     const bool xm = (g2 + G.gxm2) * 0.998f < cur, xp = (g2 + G.gxp2) * 0.998f < cur;
                     a = xm ? rb.s0 : rb.s1;
                     b = xp ? rb.s3 : rb.s2;
