@@ -1347,7 +1347,11 @@ __global__ __launch_bounds__(BLK) void k_ref_fused(SfGrid g, SfWindow w, const f
     __syncthreads();
     if (threadIdx.x == 0) S.n_points = n;
     uint32_t *ctr = bar + 2 * b, *fin = bar + 2 * b + 1;
-    double *slab = partials + (size_t)b * nblocks * REC_STRIDE;
+    // TWO slabs per scan, used in turn: a workgroup that is through a barrier may write its next row while a slower one is
+    // still summing the rows of the record before (there is one barrier per record, between writing and reading; found by
+    // the soak tests as a rare last-bits difference under load).  Nobody can be more than one record ahead -- the next
+    // barrier needs everybody's arrival -- so two buffers are enough.
+    double *const slab_even = partials + (size_t)b * nblocks * REC_STRIDE, *const slab_odd = partials + ((size_t)gridDim.y + b) * nblocks * REC_STRIDE;
     const int i = bx * BLK + (int)threadIdx.x;
     float x = 0.0f, y = 0.0f, z = 0.0f, tx = 0.0f, ty = 0.0f, tz = 0.0f;
     int corr = -1;
@@ -1401,6 +1405,7 @@ __global__ __launch_bounds__(BLK) void k_ref_fused(SfGrid g, SfWindow w, const f
             acc[13] += sz * px; acc[14] += sz * py; acc[15] += sz * pz;
             acc[16] += (double)nrm;
         }
+        double *slab = (passed & 1u) ? slab_odd : slab_even;
         block_reduce_store<NREC_P2P>(acc, slab + (size_t)bx * REC_STRIDE);
         FTRACE(2);
         ++passed;
@@ -1472,7 +1477,7 @@ __global__ __launch_bounds__(BLK) void k_icp_fused(SfGrid g, SfWindow w, const f
     for (int k = threadIdx.x; k < (int)(sizeof(IcpState) / 4); k += BLK) reinterpret_cast<uint32_t *>(&S)[k] = reinterpret_cast<const uint32_t *>(st + b)[k];
     __syncthreads();
     uint32_t *ctr = bar + 2 * b, *fin = bar + 2 * b + 1;
-    double *slab = partials + (size_t)b * nblocks * REC_STRIDE;
+    double *const slab_even = partials + (size_t)b * nblocks * REC_STRIDE, *const slab_odd = partials + ((size_t)gridDim.y + b) * nblocks * REC_STRIDE; // used in turn: see k_ref_fused
     const int slot = bx * BLK + (int)threadIdx.x;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool have = slot < n;
@@ -1533,6 +1538,7 @@ __global__ __launch_bounds__(BLK) void k_icp_fused(SfGrid g, SfWindow w, const f
             }
         }
         __syncthreads();
+        double *slab = (passed & 1u) ? slab_odd : slab_even;
         if (threadIdx.x < NREC) {
             const int c = threadIdx.x;
             slab[(size_t)bx * REC_STRIDE + c] = ((stage[0][c] + stage[1][c]) + stage[2][c]) + stage[3][c];
@@ -2011,6 +2017,8 @@ int launch_fused(sf_icp *icp, int mode)
         SF_TRY(icp->bar.reserve(need));
         SF_HIP(hipMemsetAsync(icp->bar.p, 0, icp->bar.cap, s)); // afterwards the kernel leaves the counters at zero itself
     }
+    // two slabs per scan (see k_ref_fused)
+    SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)REC_STRIDE * (size_t)std::max(icp->nblocks, icp->nblocks_nn) * (size_t)B * 2));
     if (mode != SF_ICP_REF_CPP) {
         const dim3 grid_nn((unsigned)icp->nblocks_nn, (unsigned)B);
         if (mode == SF_ICP_O3D_P2P) launch_icp_fused<1>(icp, grid_nn);

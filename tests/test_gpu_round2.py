@@ -353,6 +353,48 @@ def test_single_launch_fuzz_against_launch_list(api, ctx, synth, small_world):
     mp.window_none()
 
 
+def test_single_launch_under_concurrent_load(api, ctx, synth, small_world):
+    """The grid barriers' release / acquire hand-off is easiest to get wrong where an idle chip hides it: the
+    single-launch alignments are repeated while a second stream keeps the device busy with large batched alignments
+    (uneven load, caches warm with other data) -- every repetition must reproduce the launch list's result bit for bit."""
+    m = small_world["map"]
+    mp = api.Map(ctx, api.Cloud(ctx, m), 0.25)
+    mp.estimate_normals(0.25)
+    busy_ctx = api.Context(0)
+    busy_map = api.Map(busy_ctx, api.Cloud(busy_ctx, m), 0.25)
+    busy_map.estimate_normals(0.25)
+    big = np.stack([synth.make_scan(m, 60000, scan_id=900 + k)[0] for k in range(8)])
+    busy = api.Icp(busy_ctx, 0.5, 20, 0.05, 1e-5)
+    busy.set_fused(False)
+    busy.set_target(busy_map)
+    busy.set_source_batch(big)
+    busy.set_initial_batch(None)
+    keys = ("iterations", "converged", "n_corr", "n_research", "flags")
+    cases = []
+    for k, (mode, n) in enumerate([("ref_cpp", 9000), ("o3d_p2p", 5000), ("p2plane", 13000), ("ref_cpp", 700)]):
+        scan = synth.make_scan(m, n, scan_id=950 + k)[0]
+        init = synth.make_T((0.03, -0.02, 0.01), (0, 0.1, 0.4)).astype(np.float32)
+        ref = api.Icp(ctx, 0.5, 12, 0.001, 1e-5)
+        ref.set_fused(False)
+        ref.set_target(mp)
+        ref.set_source(scan)
+        ref.set_initial_transformation(init)
+        one = api.Icp(ctx, 0.5, 12, 0.001, 1e-5)
+        one.set_target(mp)
+        one.set_source(scan)
+        one.set_initial_transformation(init)
+        cases.append((mode, one, ref.align(mode)))
+    reps = 120
+    for rep in range(reps):
+        for _ in range(3):
+            busy.align_batch_async("p2plane")                            # ~1 ms of device work each, queued ahead on the other stream
+        for mode, one, expect in cases:
+            r = one.align(mode)
+            assert np.array_equal(r["T64"], expect["T64"]) and all(r[k] == expect[k] for k in keys), (rep, mode)
+    busy_ctx.synchronize()
+    assert all(one.fused_count() == reps for _, one, _ in cases)
+
+
 def test_large_sparse_extents_index_at_a_fine_cell(api, ctx, orc, synth):
     """The dense cell table may take a quarter of the device's free memory: an explicit 0.25 m cell over a
     1 km x 1 km x 100 m extent (6.4e9 cells, 64-bit cell ids, 25.6 GB of the 288 GB) and over 500 m x 500 m x 50 m
