@@ -827,10 +827,11 @@ class Node:
     def _messages(self, gps, odom):
         g, o = self._gps, self._odom
         g.latitude, g.longitude, g.altitude = gps["latitude"], gps["longitude"], gps["altitude"]
-        g.position_covariance[:] = gps["position_covariance"]
-        o.q_wxyz[:] = odom["q_wxyz"]
-        o.t[:] = odom["t"]
-        o.covariance[:] = odom["covariance"]
+        for dst, src, n in ((g.position_covariance, gps["position_covariance"], 9), (o.q_wxyz, odom["q_wxyz"], 4), (o.t, odom["t"], 3), (o.covariance, odom["covariance"], 36)):
+            a = np.ascontiguousarray(src, dtype=np.float64)           # one block copy instead of a Python-level loop over the elements
+            if a.size != n:
+                raise SlamFusionError("message field has %d values, %d expected" % (a.size, n))
+            C.memmove(dst, a.ctypes.data, 8 * n)
         return g, o
 
     def callback(self, scan, gps, odom):

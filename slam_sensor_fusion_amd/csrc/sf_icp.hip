@@ -1334,7 +1334,7 @@ __device__ __forceinline__ bool ref_grid_barrier(uint32_t *ctr, uint32_t target,
 template <bool WINDOW>
 __global__ __launch_bounds__(BLK) void k_ref_fused(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
                                                    const int *__restrict__ n_live, IcpState *__restrict__ st, IcpParams prm, float thr, double *__restrict__ partials, int nblocks,
-                                                   uint32_t *__restrict__ bar)
+                                                   uint32_t *__restrict__ bar, IcpState *__restrict__ host_out)
 {
     const int b = blockIdx.y, bx = blockIdx.x;
     if (n_live) n = *n_live; // single scan whose count was left on the device (sf_icp_set_source_scan)
@@ -1442,11 +1442,18 @@ __global__ __launch_bounds__(BLK) void k_ref_fused(SfGrid g, SfWindow w, const f
     if (bx == 0 && b == 0 && threadIdx.x == 0) g_fused_trace[0] = (unsigned long long)tr_n;
 #endif
     if (!alive) {
-        if (threadIdx.x == 0) atomicOr(&st[b].flags, SF_ICP_FLAG_BARRIER_TIMEOUT);
+        if (threadIdx.x == 0) {
+            atomicOr(&st[b].flags, SF_ICP_FLAG_BARRIER_TIMEOUT);
+            if (host_out) host_out[b].flags = SF_ICP_FLAG_BARRIER_TIMEOUT;
+        }
         return; // the counters stay as they are: the host resets them when it sees the flag
     }
     if (bx == 0)
-        for (int k = threadIdx.x; k < (int)(sizeof(IcpState) / 4); k += BLK) reinterpret_cast<uint32_t *>(st + b)[k] = reinterpret_cast<const uint32_t *>(&S)[k];
+        for (int k = threadIdx.x; k < (int)(sizeof(IcpState) / 4); k += BLK) {
+            const uint32_t v = reinterpret_cast<const uint32_t *>(&S)[k];
+            reinterpret_cast<uint32_t *>(st + b)[k] = v;
+            if (host_out) reinterpret_cast<uint32_t *>(host_out + b)[k] = v; // pinned host memory: the result needs no copy back
+        }
     // the workgroup that leaves last puts the counters back to zero for the next launch (everybody is past its last barrier)
     if (threadIdx.x == 0) {
         const uint32_t left = __hip_atomic_fetch_add(fin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1465,7 +1472,8 @@ __global__ __launch_bounds__(BLK) void k_ref_fused(SfGrid g, SfWindow w, const f
 // Bit-identical to the launch list (same rows, same sums, same certificate; tests/test_gpu_round2.py).
 template <int MODE, bool WINDOW, bool REUSE>
 __global__ __launch_bounds__(BLK) void k_icp_fused(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
-                                                   IcpState *__restrict__ st, float thr, int K, double *__restrict__ partials, int nblocks, uint32_t *__restrict__ bar)
+                                                   IcpState *__restrict__ st, float thr, int K, double *__restrict__ partials, int nblocks, uint32_t *__restrict__ bar,
+                                                   IcpState *__restrict__ host_out)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.y, bx = blockIdx.x;
@@ -1556,11 +1564,18 @@ __global__ __launch_bounds__(BLK) void k_icp_fused(SfGrid g, SfWindow w, const f
     }
     __syncthreads();
     if (!alive) {
-        if (threadIdx.x == 0) atomicOr(&st[b].flags, SF_ICP_FLAG_BARRIER_TIMEOUT);
+        if (threadIdx.x == 0) {
+            atomicOr(&st[b].flags, SF_ICP_FLAG_BARRIER_TIMEOUT);
+            if (host_out) host_out[b].flags = SF_ICP_FLAG_BARRIER_TIMEOUT;
+        }
         return;
     }
     if (bx == 0)
-        for (int k = threadIdx.x; k < (int)(sizeof(IcpState) / 4); k += BLK) reinterpret_cast<uint32_t *>(st + b)[k] = reinterpret_cast<const uint32_t *>(&S)[k];
+        for (int k = threadIdx.x; k < (int)(sizeof(IcpState) / 4); k += BLK) {
+            const uint32_t v = reinterpret_cast<const uint32_t *>(&S)[k];
+            reinterpret_cast<uint32_t *>(st + b)[k] = v;
+            if (host_out) reinterpret_cast<uint32_t *>(host_out + b)[k] = v;
+        }
     if (threadIdx.x == 0) {
         const uint32_t left = __hip_atomic_fetch_add(fin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (left == (uint32_t)nblocks - 1u) {
@@ -1629,6 +1644,8 @@ struct sf_icp {
     sf::DevBuf bar;          // per scan: {arrival counter, departure counter} of the grid barrier
     int fused_limit[3] = {-1, -1, -1}; // per mode: workgroups that are certainly resident together (-1: not asked yet)
     int64_t fused_launches = 0;
+    IcpState *h_pin = nullptr; // pinned, device-visible: the single-launch forms write the final states here themselves (no copy back)
+    size_t h_pin_cap = 0;
     // graph
     bool use_graph = false;
     hipGraphExec_t graph_exec = nullptr;
@@ -1999,7 +2016,7 @@ void launch_icp_fused(sf_icp *icp, dim3 grid)
     const bool win = m->window.kind != 0;
 #define SF_LAUNCH_ICPF(W, R)                                                                                                                                               \
     hipLaunchKernelGGL((k_icp_fused<MODE, W, R>), grid, dim3(BLK), 0, s, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n, icp->state.as<IcpState>(), thr, \
-                       icp->prm.num_iters, icp->partials.as<double>(), icp->nblocks_nn, icp->bar.as<uint32_t>())
+                       icp->prm.num_iters, icp->partials.as<double>(), icp->nblocks_nn, icp->bar.as<uint32_t>(), icp->h_pin)
     if (win && icp->reuse) SF_LAUNCH_ICPF(true, true);
     else if (win) SF_LAUNCH_ICPF(true, false);
     else if (icp->reuse) SF_LAUNCH_ICPF(false, true);
@@ -2017,6 +2034,11 @@ int launch_fused(sf_icp *icp, int mode)
         SF_TRY(icp->bar.reserve(need));
         SF_HIP(hipMemsetAsync(icp->bar.p, 0, icp->bar.cap, s)); // afterwards the kernel leaves the counters at zero itself
     }
+    if (icp->h_pin_cap < (size_t)B) {
+        if (icp->h_pin) { hipError_t e = hipHostFree(icp->h_pin); (void)e; icp->h_pin = nullptr; icp->h_pin_cap = 0; }
+        SF_HIP(hipHostMalloc((void **)&icp->h_pin, sizeof(IcpState) * (size_t)B, hipHostMallocDefault));
+        icp->h_pin_cap = (size_t)B;
+    }
     // two slabs per scan (see k_ref_fused)
     SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)REC_STRIDE * (size_t)std::max(icp->nblocks, icp->nblocks_nn) * (size_t)B * 2));
     if (mode != SF_ICP_REF_CPP) {
@@ -2033,10 +2055,10 @@ int launch_fused(sf_icp *icp, int mode)
     const int *nl = icp->n_on_device ? icp->n_dev.as<int>() : nullptr;
     if (m->window.kind != 0)
         hipLaunchKernelGGL(k_ref_fused<true>, grid, dim3(BLK), 0, s, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n, nl, icp->state.as<IcpState>(), prm, thr,
-                           icp->partials.as<double>(), icp->nblocks, icp->bar.as<uint32_t>());
+                           icp->partials.as<double>(), icp->nblocks, icp->bar.as<uint32_t>(), icp->h_pin);
     else
         hipLaunchKernelGGL(k_ref_fused<false>, grid, dim3(BLK), 0, s, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n, nl, icp->state.as<IcpState>(), prm, thr,
-                           icp->partials.as<double>(), icp->nblocks, icp->bar.as<uint32_t>());
+                           icp->partials.as<double>(), icp->nblocks, icp->bar.as<uint32_t>(), icp->h_pin);
     SF_HIP(hipGetLastError());
     icp->fused_launches += 1;
     return SF_OK;
@@ -2092,11 +2114,25 @@ void fill_result(const sf_icp *icp, int mode, const IcpState &S, const double *i
     }
 }
 
-int fetch_states(sf_icp *icp)
+// the states of the last alignment on the host: copied back, or -- single-launch forms -- already written to pinned host
+// memory by the kernel itself (measured on the per-scan path: enqueueing the 608-byte copy costs more host time than the
+// kernel's stores)
+int states_to_host(sf_icp *icp)
 {
     hipStream_t s = icp->ctx->stream;
+    if (icp->last_fused && icp->h_pin) {
+        SF_HIP(hipStreamSynchronize(s));
+        std::memcpy(icp->h_state.data(), icp->h_pin, sizeof(IcpState) * (size_t)icp->batch);
+        return SF_OK;
+    }
     SF_HIP(hipMemcpyAsync(icp->h_state.data(), icp->state.p, sizeof(IcpState) * (size_t)icp->batch, hipMemcpyDeviceToHost, s));
     SF_HIP(hipStreamSynchronize(s));
+    return SF_OK;
+}
+
+int fetch_states(sf_icp *icp)
+{
+    SF_TRY(states_to_host(icp));
     if (icp->profiling) prof_collect(icp);
     return SF_OK;
 }
@@ -2127,7 +2163,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
     if (icp->inits_ev) { e = hipEventDestroy(icp->inits_ev); (void)e; }
     if (icp->h_inits) { e = hipHostFree(icp->h_inits); (void)e; }
-    icp->X0.release(); icp->X0r.release(); icp->qcache.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->bar.release(); icp->state.release(); icp->d_inits.release();
+    icp->X0.release(); icp->X0r.release(); icp->qcache.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->bar.release(); if (icp->h_pin) { hipError_t eh = hipHostFree(icp->h_pin); (void)eh; icp->h_pin = nullptr; } icp->state.release(); icp->d_inits.release();
     icp->n_dev.release(); icp->nn_stats.release(); icp->d_box.release(); icp->stage.release(); icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
@@ -2364,9 +2400,7 @@ extern "C" int sf_icp_fetch_results(sf_icp *icp, sf_icp_result *out)
 {
     SF_CHECK(icp && out, SF_ERR_INVALID, "bad arguments");
     SF_CHECK(icp->batch > 0, SF_ERR_STATE, "nothing to fetch");
-    hipStream_t s = icp->ctx->stream;
-    SF_HIP(hipMemcpyAsync(icp->h_state.data(), icp->state.p, sizeof(IcpState) * (size_t)icp->batch, hipMemcpyDeviceToHost, s));
-    SF_HIP(hipStreamSynchronize(s));
+    SF_TRY(states_to_host(icp));
     if (icp->profiling) prof_collect(icp);
     SF_TRY(check_barrier_flags(icp));
     for (int b = 0; b < icp->batch; ++b) fill_result(icp, icp->last_mode, icp->h_state[(size_t)b], &icp->inits[(size_t)b * 16], out + b);
@@ -2486,6 +2520,7 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
     SF_CHECK(first != 2 || icp->shard, SF_ERR_STATE, "resume (first = 2) is a sharded-path operation");
     SF_HIP(hipSetDevice(icp->ctx->device));
     icp->last_mode = mode;
+    icp->last_fused = false;
     if (first == 1) SF_TRY(launch_state_init(icp));
     if (icp->shard) {
         if (first) SF_TRY(shard_build(icp, first == 2));
