@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 200
+#define SF_VERSION 210
 
 typedef enum {
     SF_OK = 0,

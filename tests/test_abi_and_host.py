@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(api):
     assert len(names) >= 80
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.sf_version() == 200
+    assert lib.sf_version() == 210
 
 
 def test_no_gpu_means_loud_failure_not_fallback(api):
