@@ -215,6 +215,56 @@ def test_cpp_node_class_equals_native_flow(tmp_path, api, ctx, orc, synth):
     assert sum(e[0] for e in expect) == n_msg - 1
 
 
+def test_native_node_under_concurrent_load(api, ctx, orc, synth):
+    """The node's whole fast path (pinned staging, one-pass source, single-launch alignment, result in pinned host
+    memory) while a second stream keeps the device busy: every pose equals the one the Python mirror computes with the
+    launch list on an otherwise idle device."""
+    from slam_sensor_fusion_amd.localization_flow import LocalizationFlow, NativeLocalizationFlow
+    raw = synth.make_map(400_000, seed=31)
+    ds = orc.voxel_pcl(raw, 0.1)[0]
+    lla0 = np.array([[-22.9068, -43.1729, 12.0]])
+    mtg = orc.map_T_global(lla0, np.zeros(1, np.float32))
+    ref, nat = LocalizationFlow(ctx, ds, mtg, altitude_table=lla0), NativeLocalizationFlow(ctx, ds, mtg, altitude_table=lla0)
+    ref.icp_.set_fused(False)
+    ref.icp_.use_graph(False)
+    for f in (ref, nat):
+        f.coarse_alignment_complete_ = True
+    gps_cov, odom_cov = np.diag([0.25, 0.25, 0.25]).ravel(), np.diag([1e-4] * 6).ravel()
+    rng = np.random.default_rng(5)
+    msgs = []
+    for k in range(30):
+        truth = synth.make_T((0.15 * k - 2.0, 0.02 * k, 0.0), (0, 0, 0.5 * k))
+        msgs.append((truth, make_sensor_scan(synth, ds, truth, 9000, 700 + k)) + messages_for(truth, k, rng, gps_cov, odom_cov))
+    expect = []
+    for k, (truth, scan, gps, odom) in enumerate(msgs):                  # the reference run, nothing else on the device
+        ref.compassCallback(90.0 - k)
+        expect.append(ref.localizationCallback(scan, gps, odom))
+        if k == 0:
+            ref.map_T_sensor_ = truth.astype(np.float32)
+            ref.map_T_ref_ = truth.astype(np.float32)
+    busy_ctx = api.Context(0)
+    busy_map = api.Map(busy_ctx, api.Cloud(busy_ctx, ds), 0.25)
+    busy_map.estimate_normals(0.25)
+    busy = api.Icp(busy_ctx, 0.5, 20, 0.05, 1e-5)
+    busy.set_fused(False)
+    busy.set_target(busy_map)
+    busy.set_source_batch(np.stack([synth.make_scan(ds, 60000, scan_id=800 + k)[0] for k in range(8)]))
+    busy.set_initial_batch(None)
+    for k, (truth, scan, gps, odom) in enumerate(msgs):
+        for _ in range(3):
+            busy.align_batch_async("p2plane")
+        nat.compassCallback(90.0 - k)
+        out = nat.localizationCallback(scan, gps, odom)
+        if k == 0:
+            assert out is None and expect[0] is None
+            nat.map_T_sensor_ = truth.astype(np.float32)
+            nat.map_T_ref_ = truth.astype(np.float32)
+            continue
+        assert np.array_equal(out, expect[k]), k
+    busy_ctx.synchronize()
+    assert nat.icp_.fused_count() == len(msgs) - 1 and ref.icp_.fused_count() == 0
+
+
 def api_o3d(api, ctx, mp, cloud, init):
     icp = api.Icp(ctx, 0.5, 10, 0.001, 1e-5)
     icp.set_target(mp)
