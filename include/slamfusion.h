@@ -241,8 +241,9 @@ int sf_icp_use_graph(sf_icp *icp, int on); /* replay the launch sequence as a hi
  * cache key keeps changing).  REF_CPP with ONE scan reads the scan's point count and the map window from device memory,
  * so scans of similar size (same count rounded up to 4096) and a moving window replay the same graph. */
 int sf_icp_graph_counts(sf_icp *icp, int64_t *captures, int64_t *launches);
-/* Alignments small enough for every workgroup to be resident at once (the nodes' per-scan paths: ~13 k points; up to
- * 65 k points in REF_CPP, 131 k in the float64 modes, summed over the batch) run as ONE launch -- search, record,
+/* Alignments small enough for every workgroup to be resident at once (the nodes' per-scan paths: ~13 k points; on MI355X
+ * up to 65 k points in REF_CPP and O3D_P2P, 131 k in P2PLANE, summed over the batch -- from the occupancy query, minus one
+ * workgroup per CU) run as ONE launch -- search, record,
  * controller / solve and step behind in-kernel grid barriers (REF_CPP: icp_point_to_point.cpp:185-254), bit-identical to
  * the launch list; on by default, larger alignments, sharded and profiled ones take the launch list.
  * sf_icp_fused_count: how many alignments have taken the single-launch form since creation. */
