@@ -826,7 +826,8 @@ __global__ void k_own_resume(IcpState *__restrict__ st, int batch)
 }
 
 __global__ __launch_bounds__(BLK) void k_own_count(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
-                                                   const IcpState *__restrict__ st, float xlo, float xhi, float margin, uint32_t *__restrict__ blk_counts, int nblocks)
+                                                   const IcpState *__restrict__ st, float xlo, float xhi, float margin, uint32_t *__restrict__ blk_counts, int nblocks,
+                                                   unsigned long long *__restrict__ wave_keep)
 {
     const int b = blockIdx.y;
     const IcpState *S = st + b;
@@ -839,7 +840,12 @@ __global__ __launch_bounds__(BLK) void k_own_count(const float *__restrict__ X0x
     }
     __shared__ uint32_t wcnt[BLK / 64];
     const unsigned long long bal = __ballot(keep);
-    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+    if ((threadIdx.x & 63) == 0) {
+        wcnt[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+        // the screening result of this wave, kept for the scatter pass: every rank screens ALL points of every scan in
+        // flight (the O(world) part of a rank's work), the second pass then reads 1 bit per point instead of the point
+        wave_keep[((size_t)b * nblocks + blockIdx.x) * (BLK / 64) + (threadIdx.x >> 6)] = bal;
+    }
     __syncthreads();
     if (threadIdx.x == 0) blk_counts[(size_t)b * nblocks + blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
@@ -878,27 +884,18 @@ __global__ __launch_bounds__(1024) void k_own_scan(const IcpState *__restrict__ 
 }
 
 // own_idx[own_off[b] + rank within the scan] = global query index b * n + i
-__global__ __launch_bounds__(BLK) void k_own_scatter(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
-                                                     const IcpState *__restrict__ st, float xlo, float xhi, float margin, const uint32_t *__restrict__ blk_off, int nblocks,
-                                                     const uint32_t *__restrict__ own_off, uint32_t *__restrict__ own_idx)
+__global__ __launch_bounds__(BLK) void k_own_scatter(int n, const IcpState *__restrict__ st, const unsigned long long *__restrict__ wave_keep, const uint32_t *__restrict__ blk_off,
+                                                     int nblocks, const uint32_t *__restrict__ own_off, uint32_t *__restrict__ own_idx)
 {
     const int b = blockIdx.y;
-    const IcpState *S = st + b;
-    if (S->done) return;
+    if (st[b].done) return;
     const int i = blockIdx.x * BLK + threadIdx.x;
-    bool keep = false;
-    if (i < n) {
-        const size_t o = (size_t)b * n + i;
-        keep = own_candidate(S, X0x[o], X0y[o], X0z[o], xlo, xhi, margin);
-    }
-    __shared__ uint32_t wcnt[BLK / 64];
-    const unsigned long long bal = __ballot(keep);
     const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) wcnt[wv] = (uint32_t)__popcll(bal);
-    __syncthreads();
-    if (!keep) return;
+    const unsigned long long *wk = wave_keep + ((size_t)b * nblocks + blockIdx.x) * (BLK / 64); // k_own_count's ballots of this workgroup
+    const unsigned long long bal = wk[wv];
+    if (!((bal >> (threadIdx.x & 63)) & 1ull)) return;
     uint32_t off = own_off[b] + blk_off[(size_t)b * nblocks + blockIdx.x];
-    for (int k = 0; k < wv; ++k) off += wcnt[k];
+    for (int k = 0; k < wv; ++k) off += (uint32_t)__popcll(wk[k]);
     own_idx[off + own_lane_rank(bal)] = (uint32_t)((size_t)b * n + i);
 }
 
@@ -1630,7 +1627,7 @@ struct sf_icp {
     // sharding
     bool shard = false;
     float xlo = 0, xhi = 0;
-    sf::DevBuf own_idx, own_blk, own_count, own_off; // sharded path: owned-query compaction
+    sf::DevBuf own_idx, own_blk, own_count, own_off, own_keep; // sharded path: owned-query compaction (own_keep: the screening ballots, 1 bit per point)
     std::vector<uint32_t> h_own;                      // host copy of counts / offsets
     int64_t own_total = 0;                            // owned-query candidates of this rank (all scans)
     float own_margin = 1.0f;                          // sf_icp_set_shard_margin
@@ -2164,7 +2161,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     if (icp->inits_ev) { e = hipEventDestroy(icp->inits_ev); (void)e; }
     if (icp->h_inits) { e = hipHostFree(icp->h_inits); (void)e; }
     icp->X0.release(); icp->X0r.release(); icp->qcache.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->bar.release(); if (icp->h_pin) { hipError_t eh = hipHostFree(icp->h_pin); (void)eh; icp->h_pin = nullptr; } icp->state.release(); icp->d_inits.release();
-    icp->n_dev.release(); icp->nn_stats.release(); icp->d_box.release(); icp->stage.release(); icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release();
+    icp->n_dev.release(); icp->nn_stats.release(); icp->d_box.release(); icp->stage.release(); icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release(); icp->own_keep.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
     sf_ctx *ctx = icp->ctx;
@@ -2479,7 +2476,8 @@ int shard_build(sf_icp *icp, bool resume)
     const float *X = soa(icp->X0, icp->plane, 0), *Y = soa(icp->X0, icp->plane, 1), *Z = soa(icp->X0, icp->plane, 2);
     const dim3 grid((unsigned)nbf, (unsigned)B);
     if (resume) hipLaunchKernelGGL(k_own_resume, dim3(nblk(B, 64)), dim3(64), 0, s, st, B);
-    hipLaunchKernelGGL(k_own_count, grid, dim3(BLK), 0, s, X, Y, Z, n, st, icp->xlo, icp->xhi, icp->own_margin, icp->own_blk.as<uint32_t>(), nbf);
+    SF_TRY(icp->own_keep.reserve(sizeof(unsigned long long) * (size_t)nbf * (size_t)B * (BLK / 64)));
+    hipLaunchKernelGGL(k_own_count, grid, dim3(BLK), 0, s, X, Y, Z, n, st, icp->xlo, icp->xhi, icp->own_margin, icp->own_blk.as<uint32_t>(), nbf, icp->own_keep.as<unsigned long long>());
     hipLaunchKernelGGL(k_own_scan, dim3((unsigned)B), dim3(1024), 0, s, st, icp->own_blk.as<uint32_t>(), nbf, icp->own_count.as<uint32_t>());
     icp->h_own.assign((size_t)B + 1, 0u);
     SF_HIP(hipMemcpyAsync(icp->h_own.data() + 1, icp->own_count.p, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
@@ -2497,7 +2495,7 @@ int shard_build(sf_icp *icp, bool resume)
     SF_TRY(icp->own_idx.reserve(sizeof(uint32_t) * cap));
     SF_TRY(icp->Xq.reserve(sizeof(float) * 3 * cap));
     if (own > 0) {
-        hipLaunchKernelGGL(k_own_scatter, grid, dim3(BLK), 0, s, X, Y, Z, n, st, icp->xlo, icp->xhi, icp->own_margin, icp->own_blk.as<uint32_t>(), nbf, icp->own_off.as<uint32_t>(),
+        hipLaunchKernelGGL(k_own_scatter, grid, dim3(BLK), 0, s, n, st, icp->own_keep.as<unsigned long long>(), icp->own_blk.as<uint32_t>(), nbf, icp->own_off.as<uint32_t>(),
                            icp->own_idx.as<uint32_t>());
         // cell-order every scan's candidates and gather them into the compact arrays (segments = own_off, elements ->
         // global query ids = own_idx); with an empty map every key is equal and the stable sort keeps the compacted order
