@@ -14,7 +14,7 @@ timeout -k 10 300 python3 bench.py --no-nn-reuse --no-cpu-baseline --no-extras 2
 timeout -k 10 300 python3 bench.py --force-dist --no-cpu-baseline --no-extras 2>/dev/null | line > "$OUT/${P}_bench_forcedist.json"; echo forcedist
 timeout -k 10 300 python3 bench.py --force-dist --collective torch --no-cpu-baseline --no-extras 2>/dev/null | line > "$OUT/${P}_bench_forcedist_torch.json"; echo forcedist_torch
 : > "$OUT/${P}_bench_sweep.jsonl"
-for b in 1 2 4 8 16 64; do timeout -k 10 300 python3 bench.py --batch $b --no-cpu-baseline --no-extras 2>/dev/null | line >> "$OUT/${P}_bench_sweep.jsonl"; done; echo sweep
+for b in 1 2 4 8 16 32 128; do timeout -k 10 300 python3 bench.py --batch $b --no-cpu-baseline --no-extras 2>/dev/null | line >> "$OUT/${P}_bench_sweep.jsonl"; done; echo sweep
 : > "$OUT/${P}_stream_demo.jsonl"
 timeout -k 10 300 python3 tools/stream_demo.py --scans 1000 2>/dev/null | tail -1 >> "$OUT/${P}_stream_demo.jsonl"
 timeout -k 10 300 python3 tools/stream_demo.py --scans 1000 --python-flow 2>/dev/null | tail -1 >> "$OUT/${P}_stream_demo.jsonl"
