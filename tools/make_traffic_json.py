@@ -6,7 +6,7 @@ import json
 import sys
 
 prefix = sys.argv[1]
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 mode = sys.argv[3] if len(sys.argv) > 3 else "p2plane"
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 reuse = (sys.argv[5] if len(sys.argv) > 5 else "reuse") == "reuse"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of a round on the GPU box and write the summaries under gpurun_out/profiles_<P>/
 # (copy what is to be judged into profiles/):
-#   tools/profile_round.sh r02                          the default bench workload (p2plane, 32 scans in flight, reuse on)
+#   tools/profile_round.sh r02                          the default bench workload (p2plane, 64 scans in flight, reuse on)
 #   tools/profile_round.sh r02_search --no-nn-reuse     extra bench.py arguments: here every query searches in every launch
 #   tools/profile_round.sh r02_refcpp --mode ref_cpp
 # Timing pass: --kernel-trace --stats.  Counter passes: --pmc only, one group per run (gpurun refuses --pmc together with
