@@ -40,7 +40,8 @@ typedef enum {
     SF_ERR_HIP = -2,      /* HIP runtime failure (message has the hipError)   */
     SF_ERR_NOMEM = -3,
     SF_ERR_STATE = -4,    /* call order (e.g. align before set_source)        */
-    SF_ERR_OVERFLOW = -5  /* index space too large for the requested grid     */
+    SF_ERR_OVERFLOW = -5, /* index space too large for the requested grid     */
+    SF_ERR_COMM = -6      /* multi-GPU: a collective timed out or was aborted by a peer; every rank of the communicator gets it */
 } sf_status;
 
 typedef struct sf_ctx sf_ctx;
@@ -294,6 +295,29 @@ int sf_comm_create(sf_ctx *ctx, int nranks, int rank, const void *id128, sf_comm
 void sf_comm_destroy(sf_comm *c);
 int sf_comm_size(const sf_comm *c, int *nranks, int *rank);
 int sf_comm_allreduce_f64(sf_comm *c, void *d_buf, int64_t count); /* in place, on the context's stream (barriers, timing) */
+/* The second transport (SURVEY.md §8e option ii): a hand-written P2P all-gather + fixed-rank-order sum.  Every rank keeps an
+ * exchange region in its device memory, exports it (hipIpc) and maps its peers'; an all-reduce is ONE single-workgroup
+ * kernel on the context's stream that stores the rank's doubles into every region, raises a flag there, waits for the
+ * peers' flags (bounded) and adds the nranks slots in rank order -- bitwise identical on every rank and run to run, a few
+ * microseconds over xGMI, and the only transport that runs 2-4 ranks as separate processes on ONE device.
+ *   sf_comm_p2p_create     this rank's region; max_count = largest all-reduce in doubles (32 x scans in flight)
+ *   sf_comm_p2p_handle     -> SF_COMM_P2P_HANDLE_BYTES the launcher hands to every rank (torch.distributed, MPI, a file)
+ *   sf_comm_p2p_connect    <- the nranks handles in rank order
+ *   sf_comm_p2p_rendezvous handle + connect through a POSIX shared-memory object `name` (ranks of one node, no launcher)
+ * A rank whose wait runs out (sf_comm_set_timeout, default 20 s) or that meets an abort raises the abort word of every
+ * region: all ranks leave their collectives and sf_comm_status / sf_icp_align_sharded return SF_ERR_COMM -- nobody is
+ * left waiting in a collective.  sf_comm_abort does that from the host (RCCL: ncclCommAbort). */
+#define SF_COMM_RCCL 0
+#define SF_COMM_P2P 1
+#define SF_COMM_P2P_HANDLE_BYTES 128
+int sf_comm_p2p_create(sf_ctx *ctx, int nranks, int rank, int64_t max_count, sf_comm **out);
+int sf_comm_p2p_handle(sf_comm *c, void *handle);
+int sf_comm_p2p_connect(sf_comm *c, const void *handles);
+int sf_comm_p2p_rendezvous(sf_comm *c, const char *name, double timeout_s);
+int sf_comm_set_timeout(sf_comm *c, double seconds);
+int sf_comm_abort(sf_comm *c);
+int sf_comm_status(sf_comm *c);
+int sf_comm_kind(const sf_comm *c);
 /* one whole pass (every iteration) enqueued; first = 1 start, 2 resume the scans that stopped stale */
 int sf_icp_align_sharded_async(sf_icp *icp, int mode, sf_comm *comm, int first);
 /* blocking: passes until no scan is stale (identical decisions on every rank), results like sf_icp_align_batch */
@@ -317,6 +341,14 @@ int sf_icp_profile_read(sf_icp *icp, int64_t *nn_launches, double *nn_ms_total);
 /* every profiled NN launch in launch order: duration [ms] and, for the fused O3D_P2P / P2PLANE kernel, how many queries and
  * waves ran the search in it (the rest kept their certified neighbour); any output may be NULL, *n = launches recorded */
 int sf_icp_profile_read_launches(sf_icp *icp, float *ms, uint32_t *searched_queries, uint32_t *searched_waves, int64_t cap, int64_t *n);
+/* the sharded path's other phases while profiling is on: per-launch durations [ms] of one kind, in order (ms NULL: count only) */
+#define SF_PROF_NN 0
+#define SF_PROF_REDUCE 1      /* slab rows -> one exchange record per scan */
+#define SF_PROF_COLLECTIVE 2  /* the all-reduce of the records (RCCL or P2P), as the stream saw it: waiting for peers included */
+#define SF_PROF_SOLVE 3       /* the identical solve on every rank */
+#define SF_PROF_SHARD_BUILD 4 /* owned-query compaction + ordering at the start / resume of an alignment (one host sync inside) */
+#define SF_PROF_KINDS 5
+int sf_icp_profile_read_phases(sf_icp *icp, int kind, float *ms, int64_t cap, int64_t *n);
 
 /* ------------------------------------------------------------------ BruteForceAlignment (start-up coarse lock) */
 /* localization/include/localization/brute_force_alignment.h:22-112 and

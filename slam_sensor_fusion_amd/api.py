@@ -17,6 +17,8 @@ SF_ICP_REF_CPP, SF_ICP_O3D_P2P, SF_ICP_P2PLANE = 0, 1, 2
 SF_VOXEL_PCL, SF_VOXEL_O3D, SF_VOXEL_PCL64 = 0, 1, 2
 SF_FLAG_VOXEL_OVERFLOW = 1
 SF_ICP_FLAG_FEW_CORR, SF_ICP_FLAG_SINGULAR, SF_ICP_FLAG_SHARD_STALE, SF_ICP_FLAG_BARRIER_TIMEOUT = 1, 2, 4, 8
+PROF_NN, PROF_REDUCE, PROF_COLLECTIVE, PROF_SOLVE, PROF_SHARD_BUILD = 0, 1, 2, 3, 4
+SF_ERR_COMM = -6
 MODES = {"ref_cpp": SF_ICP_REF_CPP, "o3d_p2p": SF_ICP_O3D_P2P, "p2plane": SF_ICP_P2PLANE}
 
 
@@ -583,6 +585,14 @@ class Icp:
         _check(self.lib.sf_icp_profile_read_launches(self.h, _p(ms), _p(q), _p(w), C.c_int64(len(ms)), C.byref(n)))
         return ms[:n.value], q[:n.value], w[:n.value]
 
+    def profile_phases(self, kind):
+        """Durations [ms] of one phase of the sharded path while profiling (PROF_REDUCE / COLLECTIVE / SOLVE / SHARD_BUILD)."""
+        n = C.c_int64()
+        _check(self.lib.sf_icp_profile_read_phases(self.h, C.c_int(kind), None, C.c_int64(0), C.byref(n)))
+        ms = np.empty(max(n.value, 1), np.float32)
+        _check(self.lib.sf_icp_profile_read_phases(self.h, C.c_int(kind), _p(ms), C.c_int64(len(ms)), C.byref(n)))
+        return ms[:n.value]
+
     def close(self):
         if self.h:
             self.lib.sf_icp_destroy(self.h)
@@ -632,7 +642,13 @@ def rccl_library_path():
 
 
 class Comm:
-    """sf_comm: an RCCL communicator on a context's stream, created from a 128-byte unique id."""
+    """sf_comm: the communicator the C side all-reduces the normal-equation records on, bound to a context's stream.
+
+    Comm(ctx, nranks, rank, unique_id)        RCCL, created from a 128-byte unique id
+    Comm.p2p(ctx, nranks, rank, max_count)    the hand-written P2P transport (hipIpc store-and-flag, fixed rank-order sum):
+                                              then .handle() -> bytes, .connect([handles in rank order]) -- or
+                                              .rendezvous(name) for ranks of one node without a launcher
+    """
 
     @staticmethod
     def unique_id():
@@ -643,15 +659,47 @@ class Comm:
         _check(lib.sf_comm_unique_id(buf))
         return bytes(buf)
 
-    def __init__(self, ctx, nranks, rank, unique_id):
+    def __init__(self, ctx, nranks, rank, unique_id=None, _p2p_max_count=None):
         self.ctx, self.lib = ctx, ctx.lib
-        path = rccl_library_path()
-        _check(self.lib.sf_comm_load_rccl(path.encode() if path else None))
         self.h = C.c_void_p()
-        assert len(unique_id) == 128
-        _check(self.lib.sf_comm_create(ctx.h, C.c_int(nranks), C.c_int(rank), C.c_char_p(unique_id) if False else (C.c_char * 128).from_buffer_copy(unique_id), C.byref(self.h)))
+        if _p2p_max_count is not None:
+            _check(self.lib.sf_comm_p2p_create(ctx.h, C.c_int(nranks), C.c_int(rank), C.c_int64(int(_p2p_max_count)), C.byref(self.h)))
+            self.kind = "p2p"
+        else:
+            path = rccl_library_path()
+            _check(self.lib.sf_comm_load_rccl(path.encode() if path else None))
+            assert len(unique_id) == 128
+            _check(self.lib.sf_comm_create(ctx.h, C.c_int(nranks), C.c_int(rank), (C.c_char * 128).from_buffer_copy(unique_id), C.byref(self.h)))
+            self.kind = "rccl"
         self.nranks, self.rank = nranks, rank
         _live.add(self)
+
+    @classmethod
+    def p2p(cls, ctx, nranks, rank, max_count):
+        return cls(ctx, nranks, rank, _p2p_max_count=max_count)
+
+    def handle(self):
+        buf = (C.c_char * 128)()
+        _check(self.lib.sf_comm_p2p_handle(self.h, buf))
+        return bytes(buf)
+
+    def connect(self, handles):
+        blob = b"".join(handles)
+        assert len(blob) == 128 * self.nranks
+        _check(self.lib.sf_comm_p2p_connect(self.h, (C.c_char * len(blob)).from_buffer_copy(blob)))
+
+    def rendezvous(self, name, timeout_s=60.0):
+        _check(self.lib.sf_comm_p2p_rendezvous(self.h, name.encode(), C.c_double(timeout_s)))
+
+    def set_timeout(self, seconds):
+        _check(self.lib.sf_comm_set_timeout(self.h, C.c_double(seconds)))
+
+    def abort(self):
+        _check(self.lib.sf_comm_abort(self.h))
+
+    def status(self):
+        """Raises SlamFusionError (SF_ERR_COMM) once a collective of this communicator timed out or was aborted."""
+        _check(self.lib.sf_comm_status(self.h))
 
     def allreduce_f64(self, ptr, count):
         _check(self.lib.sf_comm_allreduce_f64(self.h, C.c_void_p(ptr), C.c_int64(count)))

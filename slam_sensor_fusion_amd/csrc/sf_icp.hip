@@ -32,6 +32,7 @@
 #include <cfloat>
 #include <cmath>
 #include <vector>
+#include <string>
 
 namespace {
 
@@ -1670,6 +1671,8 @@ struct sf_icp {
     int64_t prof_launches = 0;
     double prof_ms = 0;
     std::vector<float> prof_each;   // duration of every profiled launch, in launch order
+    std::vector<int> ev_kind;       // SF_PROF_* of every event pair
+    std::vector<float> prof_phase[SF_PROF_KINDS]; // sharded path: durations of the other phases, in order
     sf::DevBuf nn_stats;            // per profiled k_nn_red launch: {queries that searched, waves that searched}
     int64_t nn_stats_used = 0;
     static constexpr int64_t NN_STATS_CAP = 1024;
@@ -1805,9 +1808,11 @@ int icp_set_source_device_aos(sf_icp *icp, const float *d_aos, int64_t n, int ba
     return SF_OK;
 }
 
+// HIP events around a phase of the alignment on the context's stream (profiling only).  kind 0 = the NN kernel (the
+// per-launch list of sf_icp_profile_read_launches); the sharded path also times its other phases (sf_icp_profile_read_phases)
 struct ProfScope {
     sf_icp *icp;
-    explicit ProfScope(sf_icp *i) : icp(i)
+    explicit ProfScope(sf_icp *i, int kind = SF_PROF_NN) : icp(i)
     {
         if (!icp->profiling) return;
         while (icp->ev.size() < icp->ev_used + 2) {
@@ -1815,6 +1820,8 @@ struct ProfScope {
             if (hipEventCreate(&e) != hipSuccess) { icp->profiling = false; return; }
             icp->ev.push_back(e);
         }
+        if (icp->ev_kind.size() < icp->ev_used / 2 + 1) icp->ev_kind.resize(icp->ev_used / 2 + 1);
+        icp->ev_kind[icp->ev_used / 2] = kind;
         hipError_t e = hipEventRecord(icp->ev[icp->ev_used], icp->ctx->stream);
         (void)e;
     }
@@ -1831,7 +1838,10 @@ void prof_collect(sf_icp *icp)
 {
     for (size_t k = 0; k + 1 < icp->ev_used; k += 2) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, icp->ev[k], icp->ev[k + 1]) == hipSuccess) { icp->prof_ms += ms; icp->prof_launches += 1; icp->prof_each.push_back(ms); }
+        if (hipEventElapsedTime(&ms, icp->ev[k], icp->ev[k + 1]) != hipSuccess) continue;
+        const int kind = k / 2 < icp->ev_kind.size() ? icp->ev_kind[k / 2] : SF_PROF_NN;
+        if (kind == SF_PROF_NN) { icp->prof_ms += ms; icp->prof_launches += 1; icp->prof_each.push_back(ms); }
+        else if (kind > 0 && kind < SF_PROF_KINDS) icp->prof_phase[kind].push_back(ms);
     }
     icp->ev_used = 0;
 }
@@ -2465,6 +2475,7 @@ namespace {
 // One host synchronisation (the counts size the sort and the launch grid).
 int shard_build(sf_icp *icp, bool resume)
 {
+    ProfScope ps(icp, SF_PROF_SHARD_BUILD);
     const int B = icp->batch;
     const int n = (int)icp->n;
     const int nbf = icp->nblocks; // workgroups covering a whole scan
@@ -2532,9 +2543,11 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
     const uint32_t *off = icp->shard ? icp->own_off.as<uint32_t>() : nullptr;
     if (mode == SF_ICP_O3D_P2P) {
         launch_nn_red<1>(icp, icp->shard);
+        ProfScope ps(icp, SF_PROF_REDUCE);
         hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off);
     } else {
         launch_nn_red<2>(icp, icp->shard);
+        ProfScope ps(icp, SF_PROF_REDUCE);
         hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off);
     }
     SF_HIP(hipGetLastError());
@@ -2548,6 +2561,7 @@ extern "C" int sf_icp_step_end(sf_icp *icp, int mode, int last)
     const double *x = reinterpret_cast<const double *>(sf_icp_exchange_ptr(icp, nullptr));
     hipStream_t s = icp->ctx->stream;
     const int K = icp->prm.num_iters;
+    ProfScope ps(icp, SF_PROF_SOLVE);
     if (mode == SF_ICP_O3D_P2P)
         hipLaunchKernelGGL(k_solve_only<1>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->d_box.as<ScanBox>(), icp->shard ? icp->own_margin : 0.0f);
     else
@@ -2620,12 +2634,22 @@ extern "C" int sf_icp_align_sharded_async(sf_icp *icp, int mode, sf_comm *comm, 
     SF_CHECK(icp->shard, SF_ERR_STATE, "sf_icp_set_shard first");
     SF_CHECK(first == 1 || first == 2, SF_ERR_INVALID, "first must be 1 (start) or 2 (resume)");
     const int steps = sharded_steps(icp, mode);
-    for (int k = 0; k < steps; ++k) {
-        SF_TRY(sf_icp_step_begin(icp, mode, k == 0 ? first : 0));
-        SF_TRY(sf::comm_allreduce_f64(comm, sf_icp_exchange_ptr(icp, nullptr), (int64_t)REC_STRIDE * icp->batch));
-        SF_TRY(sf_icp_step_end(icp, mode, k == steps - 1));
+    int rc = SF_OK;
+    for (int k = 0; k < steps && rc == SF_OK; ++k) {
+        rc = sf_icp_step_begin(icp, mode, k == 0 ? first : 0);
+        if (rc == SF_OK) {
+            ProfScope ps(icp, SF_PROF_COLLECTIVE);
+            rc = sf::comm_allreduce_f64(comm, sf_icp_exchange_ptr(icp, nullptr), (int64_t)REC_STRIDE * icp->batch);
+        }
+        if (rc == SF_OK) rc = sf_icp_step_end(icp, mode, k == steps - 1);
     }
-    return SF_OK;
+    // this rank stops mid-loop: its peers must not be left waiting in the collectives it will never join
+    if (rc != SF_OK && rc != SF_ERR_COMM) {
+        const std::string why = sf_last_error();
+        sf_comm_abort(comm);
+        sf::set_error("%s", why.c_str());
+    }
+    return rc;
 }
 
 // blocking form: passes until no scan is left stale (every rank takes the same decisions: the states are identical)
@@ -2638,6 +2662,7 @@ extern "C" int sf_icp_align_sharded(sf_icp *icp, int mode, sf_comm *comm, sf_icp
         for (int attempt = 0; attempt <= steps + 1; ++attempt) { // every resume completes at least one iteration
             SF_TRY(sf_icp_align_sharded_async(icp, mode, comm, first));
             SF_TRY(fetch_states(icp));
+            SF_TRY(sf_comm_status(comm)); // a collective that timed out or was aborted left the records unsummed: no result
             if (!any_stale(icp)) {
                 for (int b = 0; b < icp->batch; ++b) fill_result(icp, icp->last_mode, icp->h_state[(size_t)b], &icp->inits[(size_t)b * 16], out + b);
                 if (resumes) *resumes = n_resume;
@@ -2718,6 +2743,7 @@ extern "C" int sf_icp_profile_enable(sf_icp *icp, int on)
     icp->prof_launches = 0;
     icp->prof_ms = 0;
     icp->prof_each.clear();
+    for (auto &v : icp->prof_phase) v.clear();
     icp->nn_stats_used = 0;
     if (on) {
         SF_TRY(icp->nn_stats.reserve(sizeof(uint32_t) * 2 * NN_STATS_SHARDS * sf_icp::NN_STATS_CAP));
@@ -2733,5 +2759,20 @@ extern "C" int sf_icp_profile_read(sf_icp *icp, int64_t *nn_launches, double *nn
     prof_collect(icp);
     if (nn_launches) *nn_launches = icp->prof_launches;
     if (nn_ms_total) *nn_ms_total = icp->prof_ms;
+    return SF_OK;
+}
+
+// durations [ms] of one phase kind (SF_PROF_REDUCE, SF_PROF_COLLECTIVE, SF_PROF_SOLVE, SF_PROF_SHARD_BUILD) of the sharded
+// path since sf_icp_profile_enable, in order; ms may be NULL to ask for the count
+extern "C" int sf_icp_profile_read_phases(sf_icp *icp, int kind, float *ms, int64_t cap, int64_t *n)
+{
+    SF_CHECK(icp && kind > 0 && kind < SF_PROF_KINDS, SF_ERR_INVALID, "bad arguments");
+    SF_HIP(hipStreamSynchronize(icp->ctx->stream));
+    prof_collect(icp);
+    const std::vector<float> &v = icp->prof_phase[kind];
+    if (n) *n = (int64_t)v.size();
+    if (!ms) return SF_OK;
+    SF_CHECK(cap >= (int64_t)v.size(), SF_ERR_INVALID, "buffer too small");
+    std::memcpy(ms, v.data(), sizeof(float) * v.size());
     return SF_OK;
 }

@@ -10,6 +10,12 @@
 #include "sf_common.hpp"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -67,11 +73,156 @@ const char *rccl_error(int rc) { return g_rccl.error_string ? g_rccl.error_strin
 
 } // namespace
 
+// ------------------------------------------------------------------ P2P transport (option ii)
+// The record all-reduce without RCCL: every rank owns an exchange region in its device memory (uncached, so that neither
+// a per-XCD L2 nor a peer's cache keeps a stale copy), exports it as a hipIpc handle and maps its peers' regions.  Per
+// all-reduce ONE kernel of one workgroup runs on the context's stream:
+//   publish  every thread stores its elements of the local buffer into slot[parity][me] of EVERY rank's region (its own
+//            included) with system-scope stores; every wave drains its stores, workgroup barrier, lane 0 system-scope
+//            release fence, then lane r stores the sequence number into flag[me] of rank r's region;
+//   wait     lane r polls flag[r] of the OWN region (relaxed system-scope loads, s_sleep) until it reaches the sequence
+//            number -- bounded by a wall-clock limit and by the region's abort word; one system-scope acquire fence;
+//   sum      every thread adds the nranks slots of its elements in FIXED RANK ORDER and writes the local buffer: the
+//            result is bitwise identical on every rank and from run to run (an RCCL ring promises neither).
+// Slots are double-buffered by the parity of the sequence number: a rank can pass the wait of collective k+1 only after
+// every peer has published k+1, i.e. has finished reading k, so writing k+2 into the slots of k is safe.
+// A rank that times out (a peer died or never arrived) or finds the abort word set raises the abort word of EVERY
+// region it can reach and its own status word (pinned host memory): all ranks leave their collectives at once and
+// sf_comm_status / sf_icp_align_sharded report SF_ERR_COMM instead of waiting in a collective.  sf_comm_abort does the
+// same from the host (an error return on one rank mid-loop).  The same code serves 2-4 ranks as separate processes on ONE
+// device (how the sharded loop is tested on a one-GPU box) and 8 ranks over xGMI.
+namespace {
+
+constexpr int P2P_MAX_RANKS = 16;
+constexpr uint32_t P2P_MAGIC = 0x32504653u; // "SFP2"
+constexpr size_t P2P_LINE = 128;
+constexpr size_t P2P_FLAGS_OFF = 0;                                  // uint64 flag[r] at r * 128
+constexpr size_t P2P_ABORT_OFF = P2P_LINE * P2P_MAX_RANKS;           // uint32
+constexpr size_t P2P_SLOTS_OFF = P2P_ABORT_OFF + 2 * P2P_LINE;       // double slot[2][nranks][max_count]
+constexpr int P2P_BLK = 1024;
+
+struct P2pHandle { // SF_COMM_P2P_HANDLE_BYTES: what the launcher hands round
+    uint32_t magic;
+    int32_t rank, nranks, device;
+    int64_t pid;
+    int64_t max_count;
+    uint64_t region_bytes;
+    uint64_t ptr; // same-process peers (several contexts in one process) use the pointer itself
+    hipIpcMemHandle_t ipc;
+    char pad[128 - 48 - sizeof(hipIpcMemHandle_t)];
+};
+static_assert(sizeof(P2pHandle) == SF_COMM_P2P_HANDLE_BYTES, "handle blob size");
+
+struct P2pPeers { unsigned char *region[P2P_MAX_RANKS]; int nranks, rank; };
+
+__device__ __forceinline__ unsigned long long *p2p_flag(unsigned char *region, int r) { return reinterpret_cast<unsigned long long *>(region + P2P_FLAGS_OFF + (size_t)r * P2P_LINE); }
+__device__ __forceinline__ uint32_t *p2p_abort(unsigned char *region) { return reinterpret_cast<uint32_t *>(region + P2P_ABORT_OFF); }
+__device__ __forceinline__ double *p2p_slot(unsigned char *region, int parity, int r, int nranks, int64_t max_count)
+{
+    return reinterpret_cast<double *>(region + P2P_SLOTS_OFF) + ((size_t)parity * (size_t)nranks + (size_t)r) * (size_t)max_count;
+}
+
+// status word (pinned host memory): 0 ok, 1 timed out waiting for a peer, 2 aborted by a peer / the host
+__global__ __launch_bounds__(P2P_BLK) void k_p2p_allreduce(P2pPeers pr, double *__restrict__ buf, int count, int64_t max_count, unsigned long long seq, long long spin_ticks,
+                                                          uint32_t *__restrict__ status)
+{
+    __shared__ int verdict; // 0 ok, 1 timeout, 2 abort
+    const int tid = (int)threadIdx.x, R = pr.nranks, me = pr.rank, par = (int)(seq & 1ull);
+    unsigned char *mine = pr.region[me];
+    if (tid == 0) verdict = __hip_atomic_load(p2p_abort(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 2 : 0;
+    __syncthreads();
+    if (verdict == 0) {
+        // publish
+        for (int i = tid; i < count; i += P2P_BLK) {
+            const double v = buf[i];
+            for (int r = 0; r < R; ++r) __hip_atomic_store(p2p_slot(pr.region[r], par, me, R, max_count) + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        // signal, then wait for every rank's signal (lane r: rank r)
+        if (tid < R) {
+            __hip_atomic_store(p2p_flag(pr.region[tid], me), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const long long t0 = wall_clock64();
+            int v = 0;
+            while (__hip_atomic_load(p2p_flag(mine, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__hip_atomic_load(p2p_abort(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { v = 2; break; }
+                if (wall_clock64() - t0 > spin_ticks) { v = 1; break; }
+            }
+            if (v) atomicMax(&verdict, v);
+        }
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+    if (verdict != 0) { // poison every region this rank reaches, report, leave the buffer alone
+        if (tid < R) __hip_atomic_store(p2p_abort(pr.region[tid]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u)
+            __hip_atomic_store(status, (uint32_t)verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    // sum in rank order
+    for (int i = tid; i < count; i += P2P_BLK) {
+        double s = 0.0;
+        for (int r = 0; r < R; ++r) s += __hip_atomic_load(p2p_slot(mine, par, r, R, max_count) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        buf[i] = s;
+    }
+}
+
+__global__ void k_p2p_abort(P2pPeers pr)
+{
+    const int tid = (int)threadIdx.x;
+    if (tid < pr.nranks && pr.region[tid]) __hip_atomic_store(p2p_abort(pr.region[tid]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+} // namespace
+
 struct sf_comm {
     sf_ctx *ctx = nullptr;
-    void *comm = nullptr; // ncclComm_t
     int nranks = 1, rank = 0;
+    int kind = SF_COMM_RCCL;
+    // RCCL
+    void *comm = nullptr; // ncclComm_t
+    // P2P
+    unsigned char *region = nullptr; // this rank's exchange region (device memory, uncached)
+    size_t region_bytes = 0;
+    int64_t max_count = 0;
+    P2pPeers peers{};
+    bool opened[P2P_MAX_RANKS] = {};  // peers mapped through hipIpcOpenMemHandle
+    bool connected = false;
+    unsigned long long seq = 0;       // collectives enqueued so far (every rank counts the same)
+    uint32_t *status = nullptr;       // pinned, device-visible
+    double timeout_s = 20.0;
+    int64_t n_collectives = 0;
 };
+
+namespace {
+
+int p2p_status_to_rc(const sf_comm *c)
+{
+    const uint32_t st = c->status ? *reinterpret_cast<volatile uint32_t *>(c->status) : 0u;
+    if (st == 0u) return SF_OK;
+    sf::set_error(st == 1u ? "P2P collective: rank %d of %d timed out waiting for a peer (%.1f s); every rank of the communicator has been told to stop"
+                           : "P2P collective: rank %d of %d was stopped by a peer's (or the host's) abort", c->rank, c->nranks, c->timeout_s);
+    return SF_ERR_COMM;
+}
+
+void p2p_release(sf_comm *c)
+{
+    for (int r = 0; r < c->nranks && r < P2P_MAX_RANKS; ++r)
+        if (c->opened[r] && c->peers.region[r]) { hipError_t e = hipIpcCloseMemHandle(c->peers.region[r]); (void)e; c->opened[r] = false; }
+    if (c->region) { hipError_t e = hipFree(c->region); (void)e; c->region = nullptr; }
+    if (c->status) { hipError_t e = hipHostFree(c->status); (void)e; c->status = nullptr; }
+}
+
+} // namespace
 
 extern "C" int sf_comm_load_rccl(const char *library_path) { return rccl_load(library_path); }
 
@@ -111,12 +262,203 @@ extern "C" int sf_comm_create(sf_ctx *ctx, int nranks, int rank, const void *id1
     return SF_OK;
 }
 
+// P2P, step 1: this rank's region.  max_count = the largest all-reduce (doubles) the communicator will carry.
+extern "C" int sf_comm_p2p_create(sf_ctx *ctx, int nranks, int rank, int64_t max_count, sf_comm **out)
+{
+    SF_CHECK(ctx && out && nranks >= 1 && nranks <= P2P_MAX_RANKS && rank >= 0 && rank < nranks && max_count >= 1 && max_count <= (1ll << 24), SF_ERR_INVALID,
+             "bad arguments (1..%d ranks, 1..2^24 doubles)", P2P_MAX_RANKS);
+    SF_HIP(hipSetDevice(ctx->device));
+    sf_comm *c = new (std::nothrow) sf_comm();
+    SF_CHECK(c, SF_ERR_NOMEM, "out of host memory");
+    c->kind = SF_COMM_P2P;
+    c->ctx = ctx;
+    c->nranks = nranks;
+    c->rank = rank;
+    c->max_count = max_count;
+    c->region_bytes = P2P_SLOTS_OFF + sizeof(double) * 2 * (size_t)nranks * (size_t)max_count;
+    void *p = nullptr;
+    // uncached: peers' stores must never meet a stale line in an L2 of this device
+    hipError_t e = hipExtMallocWithFlags(&p, c->region_bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, c->region_bytes, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        delete c;
+        sf::set_error("P2P exchange region (%zu bytes, uncached): %s", c->region_bytes, hipGetErrorString(e));
+        return SF_ERR_NOMEM;
+    }
+    c->region = static_cast<unsigned char *>(p);
+    int rc = SF_OK;
+    if (hipMemset(c->region, 0, c->region_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = SF_ERR_HIP;
+    if (rc == SF_OK && hipHostMalloc((void **)&c->status, 64, hipHostMallocDefault) != hipSuccess) rc = SF_ERR_NOMEM;
+    if (rc != SF_OK) {
+        sf::set_error("P2P communicator setup failed: %s", hipGetErrorString(hipGetLastError()));
+        p2p_release(c);
+        delete c;
+        return rc;
+    }
+    std::memset(c->status, 0, 64);
+    c->peers.nranks = nranks;
+    c->peers.rank = rank;
+    c->peers.region[rank] = c->region;
+    c->connected = nranks == 1;
+    sf::ctx_retain(ctx);
+    *out = c;
+    return SF_OK;
+}
+
+// step 2: the blob the launcher hands to every other rank (torch.distributed, MPI, a file, sf_comm_p2p_rendezvous)
+extern "C" int sf_comm_p2p_handle(sf_comm *c, void *handle)
+{
+    SF_CHECK(c && handle && c->kind == SF_COMM_P2P, SF_ERR_INVALID, "not a P2P communicator");
+    P2pHandle h;
+    std::memset(&h, 0, sizeof(h));
+    h.magic = P2P_MAGIC;
+    h.rank = c->rank;
+    h.nranks = c->nranks;
+    h.device = c->ctx->device;
+    h.pid = (int64_t)getpid();
+    h.max_count = c->max_count;
+    h.region_bytes = c->region_bytes;
+    h.ptr = (uint64_t)(uintptr_t)c->region;
+    if (c->nranks > 1) SF_HIP(hipIpcGetMemHandle(&h.ipc, c->region));
+    std::memcpy(handle, &h, sizeof(h));
+    return SF_OK;
+}
+
+// step 3: map the peers (handles: nranks blobs in rank order, this rank's own included)
+extern "C" int sf_comm_p2p_connect(sf_comm *c, const void *handles)
+{
+    SF_CHECK(c && handles && c->kind == SF_COMM_P2P, SF_ERR_INVALID, "not a P2P communicator");
+    SF_CHECK(!c->connected || c->nranks == 1, SF_ERR_STATE, "already connected");
+    SF_HIP(hipSetDevice(c->ctx->device));
+    const P2pHandle *hs = static_cast<const P2pHandle *>(handles);
+    for (int r = 0; r < c->nranks; ++r) {
+        P2pHandle h;
+        std::memcpy(&h, hs + r, sizeof(h));
+        SF_CHECK(h.magic == P2P_MAGIC && h.rank == r && h.nranks == c->nranks && h.max_count == c->max_count && h.region_bytes == c->region_bytes, SF_ERR_INVALID,
+                 "handle %d does not describe rank %d of this communicator (ranks %d, capacity %lld)", r, r, c->nranks, (long long)c->max_count);
+        if (r == c->rank) continue;
+        if (h.pid == (int64_t)getpid()) { // several ranks inside one process: the pointer is valid as it is
+            if (h.device != c->ctx->device) {
+                hipError_t e = hipDeviceEnablePeerAccess(h.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) SF_HIP(e);
+                (void)hipGetLastError();
+            }
+            c->peers.region[r] = reinterpret_cast<unsigned char *>((uintptr_t)h.ptr);
+            continue;
+        }
+        void *p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h.ipc, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            sf::set_error("hipIpcOpenMemHandle(rank %d, device %d) failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set on this pool)", r, h.device, hipGetErrorString(e));
+            (void)hipGetLastError();
+            return SF_ERR_HIP;
+        }
+        c->peers.region[r] = static_cast<unsigned char *>(p);
+        c->opened[r] = true;
+    }
+    c->connected = true;
+    return SF_OK;
+}
+
+// steps 2 + 3 for ranks of ONE node without a launcher: the blobs meet in a POSIX shared-memory object `name` (the same
+// string on every rank, unique per communicator; rank 0 removes it when all ranks have read it)
+extern "C" int sf_comm_p2p_rendezvous(sf_comm *c, const char *name, double timeout_s)
+{
+    SF_CHECK(c && name && name[0] && c->kind == SF_COMM_P2P && timeout_s > 0, SF_ERR_INVALID, "bad arguments");
+    if (c->nranks == 1) return SF_OK;
+    struct Board { uint32_t posted[P2P_MAX_RANKS]; uint32_t done[P2P_MAX_RANKS]; P2pHandle blob[P2P_MAX_RANKS]; };
+    std::string path = name[0] == '/' ? std::string(name) : "/" + std::string(name);
+    const int fd = shm_open(path.c_str(), O_CREAT | O_RDWR, 0600);
+    SF_CHECK(fd >= 0, SF_ERR_STATE, "shm_open(%s): %s", path.c_str(), std::strerror(errno));
+    if (ftruncate(fd, (off_t)sizeof(Board)) != 0) { // a fresh object is zero-filled; growing an existing one to the same size changes nothing
+        const int err = errno;
+        close(fd);
+        sf::set_error("ftruncate(%s): %s", path.c_str(), std::strerror(err));
+        return SF_ERR_STATE;
+    }
+    Board *bd = static_cast<Board *>(mmap(nullptr, sizeof(Board), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0));
+    close(fd);
+    SF_CHECK(bd != MAP_FAILED, SF_ERR_STATE, "mmap(%s): %s", path.c_str(), std::strerror(errno));
+    int rc = sf_comm_p2p_handle(c, &bd->blob[c->rank]);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto late = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s; };
+    std::vector<P2pHandle> all((size_t)c->nranks);
+    if (rc == SF_OK) {
+        __atomic_store_n(&bd->posted[c->rank], 1u, __ATOMIC_RELEASE);
+        for (int r = 0; r < c->nranks && rc == SF_OK; ++r) {
+            while (__atomic_load_n(&bd->posted[r], __ATOMIC_ACQUIRE) != 1u) {
+                if (late()) { sf::set_error("P2P rendezvous %s: rank %d did not arrive within %.0f s", path.c_str(), r, timeout_s); rc = SF_ERR_COMM; break; }
+                usleep(200);
+            }
+            if (rc == SF_OK) std::memcpy(&all[(size_t)r], &bd->blob[r], sizeof(P2pHandle));
+        }
+    }
+    if (rc == SF_OK) rc = sf_comm_p2p_connect(c, all.data());
+    __atomic_store_n(&bd->done[c->rank], rc == SF_OK ? 1u : 2u, __ATOMIC_RELEASE);
+    if (c->rank == 0) { // the object may go once nobody needs it any more (or after the time limit)
+        for (int r = 0; r < c->nranks; ++r)
+            while (__atomic_load_n(&bd->done[r], __ATOMIC_ACQUIRE) == 0u && !late()) usleep(200);
+        shm_unlink(path.c_str());
+    }
+    if (rc == SF_OK) // a peer that failed to connect will never take part: do not start collectives with it
+        for (int r = 0; r < c->nranks && rc == SF_OK; ++r) {
+            while (__atomic_load_n(&bd->done[r], __ATOMIC_ACQUIRE) == 0u && !late()) usleep(200);
+            if (__atomic_load_n(&bd->done[r], __ATOMIC_ACQUIRE) != 1u) { sf::set_error("P2P rendezvous %s: rank %d could not connect", path.c_str(), r); rc = SF_ERR_COMM; }
+        }
+    munmap(bd, sizeof(Board));
+    return rc;
+}
+
+extern "C" int sf_comm_set_timeout(sf_comm *c, double seconds)
+{
+    SF_CHECK(c && seconds > 0 && seconds <= 600, SF_ERR_INVALID, "timeout must lie in (0, 600] s");
+    c->timeout_s = seconds;
+    return SF_OK;
+}
+
+// poison the communicator from the host: every rank's pending and future collectives return at once (P2P), the RCCL
+// communicator is aborted (ncclCommAbort) when the library has it
+extern "C" int sf_comm_abort(sf_comm *c)
+{
+    SF_CHECK(c, SF_ERR_INVALID, "comm is NULL");
+    if (c->kind == SF_COMM_P2P) {
+        if (c->status && *reinterpret_cast<volatile uint32_t *>(c->status) == 0u) *reinterpret_cast<volatile uint32_t *>(c->status) = 2u;
+        hipStream_t side = nullptr; // not the context's stream: a collective may be spinning on it
+        if (hipSetDevice(c->ctx->device) == hipSuccess && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess) {
+            hipLaunchKernelGGL(k_p2p_abort, dim3(1), dim3(64), 0, side, c->peers);
+            hipError_t e = hipStreamSynchronize(side);
+            (void)e;
+            e = hipStreamDestroy(side);
+            (void)e;
+        }
+        (void)hipGetLastError();
+        return SF_OK;
+    }
+    typedef int (*CommAbortFn)(void *);
+    CommAbortFn ab = g_rccl.handle ? (CommAbortFn)dlsym(g_rccl.handle, "ncclCommAbort") : nullptr;
+    if (ab && c->comm) { ab(c->comm); c->comm = nullptr; }
+    return SF_OK;
+}
+
+// 0 while every collective so far went through; SF_ERR_COMM once one timed out or was aborted (call after synchronising)
+extern "C" int sf_comm_status(sf_comm *c)
+{
+    SF_CHECK(c, SF_ERR_INVALID, "comm is NULL");
+    if (c->kind == SF_COMM_P2P) return p2p_status_to_rc(c);
+    SF_CHECK(c->comm, SF_ERR_COMM, "the RCCL communicator has been aborted");
+    return SF_OK;
+}
+
+extern "C" int sf_comm_kind(const sf_comm *c) { return c ? c->kind : SF_ERR_INVALID; }
+
 extern "C" void sf_comm_destroy(sf_comm *c)
 {
     if (!c) return;
     hipError_t e = hipStreamSynchronize(c->ctx->stream);
     (void)e;
-    if (c->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(c->comm);
+    if (c->kind == SF_COMM_P2P) p2p_release(c);
+    else if (c->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(c->comm);
     sf_ctx *ctx = c->ctx;
     delete c;
     sf::ctx_release(ctx);
@@ -135,8 +477,20 @@ sf_ctx *comm_ctx(const sf_comm *c) { return c ? c->ctx : nullptr; }
 // in-place sum of `count` float64 on the communicator's context stream (enqueue only)
 int comm_allreduce_f64(sf_comm *c, void *d_buf, int64_t count)
 {
-    SF_CHECK(c && c->comm && d_buf && count >= 0, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(c && d_buf && count >= 0, SF_ERR_INVALID, "bad arguments");
     if (count == 0) return SF_OK;
+    if (c->kind == SF_COMM_P2P) {
+        SF_CHECK(c->connected, SF_ERR_STATE, "P2P communicator is not connected (sf_comm_p2p_connect / sf_comm_p2p_rendezvous)");
+        SF_CHECK(count <= c->max_count, SF_ERR_INVALID, "all-reduce of %lld doubles exceeds the communicator's capacity %lld", (long long)count, (long long)c->max_count);
+        SF_TRY(p2p_status_to_rc(c)); // poisoned: do not enqueue more
+        c->seq += 1;
+        c->n_collectives += 1;
+        hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(P2P_BLK), 0, c->ctx->stream, c->peers, static_cast<double *>(d_buf), (int)count, c->max_count, c->seq,
+                           (long long)(c->timeout_s * 1e8), c->status); // wall_clock64 ticks at 100 MHz
+        SF_HIP(hipGetLastError());
+        return SF_OK;
+    }
+    SF_CHECK(c->comm, SF_ERR_COMM, "the RCCL communicator has been aborted");
     const int rc = g_rccl.all_reduce(d_buf, d_buf, (size_t)count, NCCL_FLOAT64, NCCL_SUM, c->comm, c->ctx->stream);
     SF_CHECK(rc == 0, SF_ERR_HIP, "ncclAllReduce: %s", rccl_error(rc));
     return SF_OK;

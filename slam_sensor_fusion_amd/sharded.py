@@ -123,6 +123,18 @@ def plan_groups(lo, hi):
     return dict(sorted(groups.items()))
 
 
+class ScanLeftItsSlabs(RuntimeError):
+    """A registration moved a scan out of the x-range its routed ranks cover: the result may lack correspondences that
+    only another rank's slab holds.  Re-register with a larger routing margin."""
+
+
+def box_x_range(box, T):
+    """x-extent of the axis-aligned box (lo[3], hi[3]) under the affine map T (extremes are at the corners)."""
+    lo, hi = box
+    xs = [T[0, 0] * (hi[0] if c & 1 else lo[0]) + T[0, 1] * (hi[1] if c & 2 else lo[1]) + T[0, 2] * (hi[2] if c & 4 else lo[2]) + T[0, 3] for c in range(8)]
+    return min(xs), max(xs)
+
+
 class RoutedRegistration:
     """One rank's side of registering a batch of scans against a map sharded into x-slabs (north_star: "RCCL
     all-reduce of the normal equations only when the submap spans tiles").
@@ -134,21 +146,28 @@ class RoutedRegistration:
     those ranks with the sharded path, all-reducing on a communicator of just those ranks.  Ranks walk the groups in
     the same sorted order, so communicators shared between ranks see their collectives in the same order.
 
+    Inside a group the first rank owns down to -inf and the last up to +inf, so no query is ever without an owner.
+    What the group's maps cover is [edges[lo] - halo, edges[hi + 1] + halo): a scan whose registration ends with points
+    outside the group's x-range widened by `slack` (= halo - correspondence distance: how far a query may leave the
+    range and still find every neighbour within the correspondence distance in the end rank's halo) raises
+    ScanLeftItsSlabs on every rank of the group -- the same decision everywhere, they hold the same pose -- instead of
+    returning a result that silently lacks the correspondences of a slab nobody asked.
+
     make_local()            -> icp-like (set_source_batch, set_initial_batch, align_batch_async, fetch_results)
     make_sharded(lo, hi)    -> (icp-like with set_shard / set_source_batch / set_initial_batch / align_sharded(mode, comm), comm)
     """
 
-    def __init__(self, rank, world, edges, route, make_local, make_sharded, margin=1.0):
+    def __init__(self, rank, world, edges, route, make_local, make_sharded, margin=1.0, slack=0.0):
         self.rank, self.world, self.edges, self.route = rank, world, np.asarray(edges, dtype=np.float64), route
-        self.make_local, self.make_sharded, self.margin = make_local, make_sharded, margin
-        self.groups, self.mine, self.resumes = {}, {}, 0
+        self.make_local, self.make_sharded, self.margin, self.slack = make_local, make_sharded, margin, slack
+        self.groups, self.mine, self.resumes, self.boxes = {}, {}, 0, {}
 
     def set_source_batch(self, scans, inits=None):
         """scans [B, n, 3] (every rank is handed the same batch), inits [B, 4, 4] or None."""
         scans = np.asarray(scans, dtype=np.float32)
         lo, hi = self.route(scans, inits, self.edges, self.margin)
         self.groups = plan_groups(lo, hi)
-        self.mine = {}
+        self.mine, self.boxes = {}, {}
         for (a, e), ids in self.groups.items():
             if not (a <= self.rank <= e):
                 continue                                      # this rank never sees these scans again
@@ -156,11 +175,24 @@ class RoutedRegistration:
                 icp, comm = self.make_local(), None
             else:
                 icp, comm = self.make_sharded(a, e)
-                icp.set_shard(float(max(self.edges[self.rank], -1e30)), float(min(self.edges[self.rank + 1], 1e30)))
+                # the group's end ranks own everything beyond the group's range: a query is never unowned
+                icp.set_shard(-1e30 if self.rank == a else float(self.edges[self.rank]), 1e30 if self.rank == e else float(self.edges[self.rank + 1]))
             icp.set_source_batch(scans[ids])
             icp.set_initial_batch(None if inits is None else np.asarray(inits, dtype=np.float64)[ids])
             self.mine[(a, e)] = (icp, comm, ids)
+            for b in ids:
+                pts = scans[b][np.isfinite(scans[b]).all(1)].astype(np.float64)
+                self.boxes[b] = (pts.min(0), pts.max(0))
         return self.groups
+
+    def check_reach(self, a, e, ids, results):
+        """Every scan of group (a, e) must end inside the x-range its ranks cover (see the class docstring)."""
+        x_lo, x_hi = self.edges[a] - self.slack, self.edges[e + 1] + self.slack
+        for b, r in zip(ids, results):
+            x0, x1 = box_x_range(self.boxes[b], np.asarray(r["T64"], dtype=np.float64).reshape(4, 4))
+            if x0 < x_lo or x1 >= x_hi:
+                raise ScanLeftItsSlabs("scan %d was routed to slabs %d..%d (x in [%g, %g) with slack) but its registration ends at x in [%g, %g]: "
+                                       "re-register with a routing margin above %g m" % (b, a, e, x_lo, x_hi, x0, x1, self.margin))
 
     def align(self, mode):
         """-> {scan id: result} for the scans this rank took part in."""
@@ -173,7 +205,10 @@ class RoutedRegistration:
                 continue
             res = icp.align_sharded(mode, comm)
             self.resumes += int(getattr(icp, "resumes", 0))
+            self.check_reach(a, e, ids, res)
             out.update(dict(zip(ids, res)))
-        for _, (icp, _, ids) in local:
-            out.update(dict(zip(ids, icp.fetch_results())))
+        for (a, e), (icp, _, ids) in local:
+            res = icp.fetch_results()
+            self.check_reach(a, e, ids, res)
+            out.update(dict(zip(ids, res)))
         return out

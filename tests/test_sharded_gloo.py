@@ -328,3 +328,62 @@ def test_routed_registration_only_spanning_scans_use_collectives(orc, synth, tmp
         coll = np.load(tmp_path / ("coll_%d.npy" % r))
         assert coll[0] == ITERS * sum(1 for a, e in multi if a <= r <= e)
         assert coll[1] == len(set(rg for rg in ranges.values() if rg == (r, r)))
+
+
+# ------------------------------------------------------------------ a scan must not leave the slabs it was routed to
+class _StubIcp:
+    """icp-like whose 'registration' returns a prescribed pose (what check_reach looks at)."""
+
+    def __init__(self, T):
+        self.T, self.shard = T, None
+
+    def set_shard(self, lo, hi):
+        self.shard = (lo, hi)
+
+    def set_source_batch(self, scans):
+        self.n = len(scans)
+
+    def set_initial_batch(self, inits):
+        pass
+
+    def align_batch_async(self, mode):
+        pass
+
+    def fetch_results(self):
+        return [dict(T64=self.T, flags=0)] * self.n
+
+    def align_sharded(self, mode, comm):
+        return self.fetch_results()
+
+
+def test_routed_registration_raises_when_a_scan_leaves_its_slabs():
+    """an initial error larger than the routing margin.  Scan 0 lies inside slab 0, scan 1 spans slabs 0..1 of
+    three; a registration that ends 2 m further along +x leaves the range the routed ranks cover and must raise on them
+    instead of returning a pose computed without the next slab's points; the end ranks of a group own to +-infinity."""
+    from slam_sensor_fusion_amd import api, sharded
+    edges = np.array([-np.inf, 0.0, 5.0, np.inf])
+    rng = np.random.default_rng(0)
+    inside = np.c_[rng.uniform(-4.0, -2.0, 200), rng.uniform(-1, 1, 200), rng.uniform(-1, 1, 200)].astype(np.float32)
+    spanning = np.c_[rng.uniform(-2.0, 2.0, 200), rng.uniform(-1, 1, 200), rng.uniform(-1, 1, 200)].astype(np.float32)
+    scans = np.stack([inside, spanning])
+    for shift, ok in ((0.5, True), (2.7, False), (4.0, False)):
+        T = np.eye(4)
+        T[0, 3] = shift
+        made = []
+
+        def make(T=T):
+            made.append(_StubIcp(T))
+            return made[-1]
+        for rank in (0, 1):
+            reg = sharded.RoutedRegistration(rank, 3, edges, api.shard_route, make_local=make, make_sharded=lambda lo, hi: (make(), None), margin=1.0, slack=0.5)
+            plan = reg.set_source_batch(scans, None)
+            assert plan == {(0, 0): [0], (0, 1): [1]}
+            if rank == 0:
+                assert made[-1].shard == (-1e30, 0.0)          # first rank of the group owns down to -inf ...
+            else:
+                assert made[-1].shard == (0.0, 1e30)           # ... the last one up to +inf, although slab 1 ends at x = 5
+            if ok or (shift == 2.7 and rank == 1):             # 2.7: only scan 0 (rank 0's) ends outside: x up to 0.7 >= 0 + slack
+                assert sorted(reg.align("p2plane")) == ([0, 1] if rank == 0 else [1])
+            else:
+                with pytest.raises(sharded.ScanLeftItsSlabs):  # 4.0: scan 1 ends at x up to 6 >= 5 + slack on both of its ranks
+                    reg.align("p2plane")
