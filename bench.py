@@ -15,9 +15,15 @@ whole ICP with scans and map already resident in HBM.  `--mode`:
 
 N > 1: the map is tile-sharded along x (equal-count slabs + halo).  Default (`--scan-kind whole`, BASELINE's
 synthetic scans: points drawn from the WHOLE map) every scan spans every tile, so every rank owns 1/N of each
-scan's queries and the 30-double normal-equation records are all-reduced over RCCL once per ICP iteration; the whole
-iteration loop incl. the collective is enqueued from the C side (sf_icp_align_sharded; falls back to
-torch.distributed stepping if the C-side communicator cannot be created).  `--scan-kind local` draws every scan
+scan's queries and the 30-double normal-equation records are all-reduced once per ICP iteration; the whole
+iteration loop incl. the collective is enqueued from the C side (sf_icp_align_sharded).  `--collective`:
+  auto   (default) create the hand-written P2P transport (hipIpc store-and-flag, fixed rank-order sum) AND the RCCL
+         communicator, verify each with a known sum, time both on the record size and use the faster one that works on
+         every rank; if neither does, torch.distributed stepping from Python
+  p2p / c / torch   that transport only (p2p / c fall back to torch stepping if they cannot be created on every rank)
+The N > 1 line carries per-rank min / max of owned queries, NN / reduce / collective / solve time per iteration and the
+owned-query build (`ranks`), the collective's measured latency (`collective`), a per-rank roofline block from the
+compulsory-traffic model, and -- weak scaling -- `value_strong`, the same run with `--batch` scans in all.  `--scan-kind local` draws every scan
 from a 10 m neighbourhood (what a sensor sees; the reference crops to 10 m, localization_node.cpp:296): scans are
 routed to the tiles they touch, one-tile scans are registered by one rank alone with no collective, spanning scans
 all-reduce on a communicator of just their ranks (sharded.RoutedRegistration).
@@ -58,8 +64,9 @@ def parse():
                     help="whole: BASELINE's scans (points drawn from the whole map); local: a 10 m neighbourhood per scan, routed to the tiles it touches")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the sharded path + collective even with one rank (rehearses the RCCL plumbing on one GPU)")
-    ap.add_argument("--collective", default="c", choices=["c", "torch"],
-                    help="c: the whole sharded iteration loop incl. RCCL from the C side (sf_icp_align_sharded); torch: step_begin / dist.all_reduce / step_end from Python")
+    ap.add_argument("--collective", default="auto", choices=["auto", "p2p", "c", "torch"],
+                    help="auto: P2P and RCCL both created, verified and timed, the faster one used; p2p: the hand-written hipIpc store-and-flag transport; "
+                         "c: RCCL from the C side; torch: step_begin / dist.all_reduce / step_end from Python")
     ap.add_argument("--mode", default="p2plane", choices=["p2plane", "o3d_p2p", "ref_cpp"])
     ap.add_argument("--cell", type=float, default=0.25)
     ap.add_argument("--query-order", default="auto", choices=["auto", "as_given", "cell"], help="sf_icp_set_query_order")
@@ -68,7 +75,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (no-reuse throughput, upload-inclusive rate, single-scan latency)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL, default); gloo only to rehearse the N>1 path with several ranks on ONE GPU (forces --collective torch)")
+                    help="nccl (= RCCL, default); gloo to rehearse the N>1 path with several ranks on ONE GPU (rendezvous and barriers only: the data "
+                         "path is --collective p2p, which works between processes on one device, or torch)")
     return ap.parse_args()
 
 
@@ -108,7 +116,26 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo")
-            args.collective = "torch"
+            if args.collective in ("auto", "c"):
+                args.collective = "p2p"              # RCCL refuses several ranks on one device; P2P works between processes on one device
+    ddev = "cuda" if (dist is not None and args.dist_backend == "nccl") else "cpu"   # where torch.distributed's own tensors live
+
+    def agree(ok):
+        """True iff `ok` holds on every rank (any failure must send every rank down the same branch)."""
+        if dist is None:
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], device=ddev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def gather_stats(obj):
+        """[obj of rank 0, ..., obj of rank N-1] on every rank (small python objects)."""
+        if dist is None or world == 1:
+            return [obj]
+        out_ = [None] * world
+        dist.all_gather_object(out_, obj)
+        return out_
+
     stream = torch.cuda.Stream()
     ctx = api.Context(device, stream.cuda_stream)
 
@@ -130,17 +157,35 @@ def main():
     if args.mode == "p2plane":
         mp.estimate_normals(normal_radius)
     B = args.batch * world if args.scaling == "weak" else args.batch
-    if args.scan_kind == "whole":
-        scans = np.stack([synth.make_scan(map_ds, args.scan_points, scan_id=b)[0] for b in range(B)])
-    else:
+
+    def make_one(b, msx=None, centers=None):
+        if args.scan_kind == "whole":
+            return synth.make_scan(map_ds, args.scan_points, scan_id=b)[0]
+        return local_scan(synth, msx, centers[b], args.scan_points, b)
+
+    msx = centers = None
+    if args.scan_kind == "local":
         msx = map_ds[np.argsort(map_ds[:, 0], kind="stable")]
         rng = np.random.Generator(np.random.PCG64(synth.SCAN_SEED - 1))
         L = float(np.sqrt(args.map_points / synth.DENSITY))
         centers = np.c_[rng.uniform(-L / 2 + 10, L / 2 - 10, B), rng.uniform(-L / 2 + 10, L / 2 - 10, B), np.zeros(B)]
-        scans = [local_scan(synth, msx, centers[b], args.scan_points, b) for b in range(B)]
-        n_min = min(len(s) for s in scans)
-        scans = np.stack([s[:n_min] for s in scans])
-        del msx
+    if world > 1 and B % world == 0:
+        # every scan is generated ONCE: rank r makes scans r*B/N .. (r+1)*B/N - 1, an all-gather hands them round
+        per = B // world
+        mine_ = [make_one(b, msx, centers) for b in range(rank * per, (rank + 1) * per)]
+        n_min = torch.tensor([min(len(s_) for s_ in mine_)], device=ddev)
+        dist.all_reduce(n_min, op=dist.ReduceOp.MIN)
+        n_min = int(n_min.item())
+        part = torch.from_numpy(np.stack([s_[:n_min] for s_ in mine_])).to(ddev)
+        full = torch.empty((B,) + tuple(part.shape[1:]), dtype=part.dtype, device=ddev)
+        dist.all_gather_into_tensor(full, part)
+        scans = full.cpu().numpy()
+        del part, full, mine_
+    else:
+        scans = [make_one(b, msx, centers) for b in range(B)]
+        n_min = min(len(s_) for s_ in scans)
+        scans = np.stack([s_[:n_min] for s_ in scans])
+    del msx
     n_scan = scans.shape[1]
 
     def new_icp(context=ctx):
@@ -152,14 +197,34 @@ def main():
         return icp
 
     # ---------------- the registration driver of this rank
-    routed, comm_kind, icp, comm, xbuf = None, "none", None, None, None
+    routed, comm_kind, icp = None, "none", None
+    coll_info = None
     my_scans = list(range(B))                     # scan ids this rank takes part in
     if not sharded_run:
         icp = new_icp()
         icp.set_source_batch(scans)
         icp.set_initial_batch(None)
     else:
-        def make_comm(lo, hi):
+        import uuid
+        job = [uuid.uuid4().hex[:10] if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(job, src=0)  # names the shared-memory rendezvous objects of this run
+        job = job[0]
+        init_timeout = float(os.environ.get("SF_COMM_INIT_TIMEOUT_S", "180"))
+        rec_count = 32 * B                          # doubles in one all-reduce of a whole batch's records
+
+        def make_p2p(lo, hi):
+            """P2P communicator of the ranks lo..hi: hipIpc handles meet in a POSIX shared-memory object (ranks of one node);
+            the rendezvous has its own time limit, nothing is left blocked when a rank does not arrive."""
+            c = api.Comm.p2p(ctx, hi - lo + 1, rank - lo, rec_count)
+            try:
+                c.rendezvous("sfb_%s_%d_%d" % (job, lo, hi), init_timeout)
+            except Exception:
+                c.close()
+                raise
+            return c
+
+        def make_rccl(lo, hi):
             """C-side RCCL communicator of the ranks lo..hi (every member calls this in the same order)."""
             ident = [None]
             if rank == lo:
@@ -170,9 +235,9 @@ def main():
             dist.broadcast_object_list(ident, src=lo, group=groups[(lo, hi)] if (lo, hi) in groups else None)
             if ident[0] is None:
                 raise RuntimeError("no RCCL unique id for ranks %d..%d" % (lo, hi))
-            # ncclCommInitRank blocks until every member has called it; should it never return (a rank lost, a bootstrap
-            # interface that cannot be reached) the bench must still finish: the call runs in a worker with a time limit and
-            # every rank then takes the torch.distributed path (the flag all-reduce below makes that decision common)
+            # ncclCommInitRank blocks until every member has called it.  Should it never return (a rank lost, a bootstrap
+            # interface that cannot be reached) a thread stays inside RCCL for good: this process must not carry on with
+            # collectives on the same device next to it, so the run ends here, non-zero, with the reason.
             import threading
             box = {}
 
@@ -183,29 +248,87 @@ def main():
                     box["err"] = e
             th = threading.Thread(target=work, daemon=True)
             th.start()
-            th.join(float(os.environ.get("SF_COMM_INIT_TIMEOUT_S", "180")))
+            th.join(init_timeout)
             if th.is_alive():
-                raise RuntimeError("RCCL communicator of ranks %d..%d did not come up in time" % (lo, hi))
+                print("bench.py: rank %d: ncclCommInitRank of ranks %d..%d did not return within %.0f s -- giving up" % (rank, lo, hi, init_timeout), file=sys.stderr, flush=True)
+                os._exit(4)
             if "err" in box:
                 raise box["err"]
             return box["comm"]
 
+        makers = {"p2p": make_p2p, "c": make_rccl}
         groups = {}
-        if args.scan_kind == "local" and world > 1:   # torch sub-groups: rendezvous for the ids (and the torch fallback's collectives)
+        if args.scan_kind == "local" and world > 1:   # torch sub-groups: rendezvous for the RCCL ids (and the torch fallback's collectives)
             groups = {rg: dist.new_group(list(range(rg[0], rg[1] + 1))) for rg in sharded.contiguous_ranges(world) if rg != (0, world - 1)}
-        ok_c = 1
-        if args.collective == "c":
+
+        def try_comm(kind, lo, hi):
+            """-> (ok, communicator of `kind` for ranks lo..hi or None on non-members); ok is the same on every rank of the WORLD
+            (every rank calls this, members or not)."""
+            c, member = None, lo <= rank <= hi
+            if member:
+                try:
+                    c = makers[kind](lo, hi)
+                except Exception as e:               # noqa: BLE001 -- any failure: every rank must take the same branch
+                    print("rank %d: %s communicator of ranks %d..%d failed: %s" % (rank, kind, lo, hi, e), file=sys.stderr)
+            if not agree(c is not None or not member):
+                if c is not None:
+                    c.close()
+                return False, None
+            return True, c
+
+        def verify_and_time(c):
+            """A known sum through the communicator (rank r contributes r + 1 + i/1024) and its latency on the record size:
+            -> microseconds per all-reduce as the slowest rank's stream saw it, or None if the sum is wrong anywhere."""
+            i_ = torch.arange(rec_count, dtype=torch.float64, device="cuda")
+            with torch.cuda.stream(stream):
+                x = (rank + 1) + i_ / 1024.0
+                c.allreduce_f64(x.data_ptr(), rec_count)
+            stream.synchronize()
+            want = world * (world + 1) / 2.0 + world * i_ / 1024.0
+            good = True
             try:
-                world_comm = make_comm(0, world - 1)
-            except Exception as e:                   # noqa: BLE001 -- any failure: every rank must take the same branch
-                print("rank %d: C-side RCCL communicator failed (%s); falling back to torch.distributed stepping" % (rank, e), file=sys.stderr)
-                ok_c, world_comm = 0, None
-            flag = torch.tensor([ok_c], device="cuda" if args.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok_c = int(flag.item())
-        else:
-            ok_c, world_comm = 0, None
-        comm_kind = "rccl from the C side (sf_icp_align_sharded)" if ok_c else "torch.distributed all_reduce per iteration (Python stepping)"
+                c.status()
+            except api.SlamFusionError:
+                good = False
+            if not agree(good and bool(torch.equal(x, want))):
+                return None
+            reps = 100
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if dist is not None:
+                dist.barrier()
+            with torch.cuda.stream(stream):
+                e0.record(stream)
+                for _ in range(reps):
+                    c.allreduce_f64(x.data_ptr(), rec_count)
+                e1.record(stream)
+            stream.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / reps * 1e3], dtype=torch.float64, device=ddev)
+            if dist is not None:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        want_kinds = {"auto": ["p2p", "c"], "p2p": ["p2p"], "c": ["c"], "torch": []}[args.collective]
+        world_comms, coll_us = {}, {}
+        for kind in want_kinds:
+            ok_, c = try_comm(kind, 0, world - 1)
+            if not ok_:
+                continue
+            us = verify_and_time(c)
+            if us is None:
+                print("rank %d: the %s communicator did not sum correctly; not used" % (rank, kind), file=sys.stderr)
+                c.close()
+                continue
+            world_comms[kind], coll_us[kind] = c, us
+        chosen = min(world_comms, key=lambda k: coll_us[k]) if world_comms else None
+        for kind, c in world_comms.items():
+            if kind != chosen:
+                c.close()
+        names = {"p2p": "hand-written P2P (hipIpc store-and-flag, fixed rank-order sum) from the C side (sf_icp_align_sharded)",
+                 "c": "RCCL from the C side (sf_icp_align_sharded)", None: "torch.distributed all_reduce per iteration (Python stepping)"}
+        comm_kind = names[chosen]
+        coll_info = {"kind": chosen or "torch", "allreduce_us_measured": coll_us, "bytes_per_allreduce": rec_count * 8,
+                     "note": "one all-reduce of the batch's 32-double records per ICP iteration; allreduce_us_measured: 100 back-to-back all-reduces of that "
+                             "size on the stream, slowest rank, measured before the run for every transport that came up and summed a known pattern correctly"}
 
         class TorchSharded:
             """Fallback: the stepping API + dist.all_reduce from Python (round-1 path), same interface as api.Icp.align_sharded."""
@@ -224,47 +347,67 @@ def main():
             def align_sharded(self, mode, comm_):
                 def allreduce():
                     with torch.cuda.stream(stream):
-                        dist.all_reduce(self.xb, group=self.group)
+                        if ddev == "cuda":
+                            dist.all_reduce(self.xb, group=self.group)
+                        else:                        # gloo rehearsal on one GPU: through the host
+                            stream.synchronize()
+                            h = self.xb.cpu()
+                            dist.all_reduce(h, group=self.group)
+                            self.xb.copy_(h)
                 drv = sharded.ShardedIcp(self.icp, mode, iters, allreduce)
                 res = drv.align()
                 self.resumes = drv.resumes
                 return res
 
-        comms = {(0, world - 1): world_comm}
+        comms = {(0, world - 1): world_comms.get(chosen)}
+        slack = normal_radius + args.cell              # = halo - correspondence distance (sharded.RoutedRegistration)
+        if chosen and args.scan_kind == "local" and world > 1:
+            # sub-group communicators: planned first, created in the same sorted order by every rank, all inside the same
+            # agreed try / fall-back as the world communicator -- one failure anywhere and EVERY rank steps through torch
+            lo_, hi_ = api.shard_route(scans, None, edges, 1.0)
+            ok_all = True
+            for (a, e) in sharded.plan_groups(lo_, hi_):
+                if a != e and (a, e) not in comms and ok_all:
+                    ok_all, comms[(a, e)] = try_comm(chosen, a, e)
+            if not ok_all:
+                for c in comms.values():
+                    if c is not None:
+                        c.close()
+                comms, chosen = {}, None
+                comm_kind, coll_info["kind"] = names[None], "torch"
 
         def make_sharded(lo, hi):
-            if ok_c:
-                if (lo, hi) not in comms:
-                    comms[(lo, hi)] = make_comm(lo, hi)
+            if chosen:
                 return new_icp(), comms[(lo, hi)]
             return TorchSharded(new_icp(), groups.get((lo, hi))), None
 
         ctx_local = api.Context(device, torch.cuda.Stream().cuda_stream) if args.scan_kind == "local" else ctx
-        routed = sharded.RoutedRegistration(rank, world, edges, api.shard_route, make_local=lambda: new_icp(ctx_local), make_sharded=make_sharded, margin=1.0)
-        if ok_c and args.scan_kind == "local":      # communicators must be created in the same order on every rank: plan first
-            lo_, hi_ = api.shard_route(scans, None, edges, 1.0)
-            for (a, e) in sharded.plan_groups(lo_, hi_):
-                if a != e and (a, e) not in comms:
-                    if a <= rank <= e:
-                        comms[(a, e)] = make_comm(a, e)
         if world == 1:                              # --force-dist: one rank, the sharded path on the whole batch (routing would call it local)
             class OneRank:
                 groups, resumes = {(0, 0): list(range(B))}, 0
 
-                def __init__(self):
+                def __init__(self, scans_):
                     self.icp, self.comm = make_sharded(0, 0)
                     self.icp.set_shard(-1e30, 1e30)
-                    self.icp.set_source_batch(scans)
+                    self.icp.set_source_batch(scans_)
                     self.icp.set_initial_batch(None)
+                    self.mine = {(0, 0): (self.icp, self.comm, list(range(len(scans_))))}
 
                 def align(self, mode):
                     res = self.icp.align_sharded(mode, self.comm)
                     self.resumes = int(getattr(self.icp, "resumes", 0))
                     return dict(enumerate(res))
-            routed = OneRank()
+
+            def make_routed(scans_):
+                return OneRank(scans_)
         else:
-            plan = routed.set_source_batch(scans, None)
-            my_scans = sorted(b for (a, e), ids in plan.items() if a <= rank <= e for b in ids)
+            def make_routed(scans_):
+                r_ = sharded.RoutedRegistration(rank, world, edges, api.shard_route, make_local=lambda: new_icp(ctx_local), make_sharded=make_sharded, margin=1.0,
+                                                slack=slack)
+                r_.set_source_batch(scans_, None)
+                return r_
+        routed = make_routed(scans)
+        my_scans = sorted(b_ for (a, e), ids in routed.groups.items() if a <= rank <= e for b_ in ids)
     setup_s = time.time() - t_setup
 
     results_box = {}
@@ -291,8 +434,9 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ddev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if routed is None:
@@ -325,6 +469,84 @@ def main():
         frac_search = sq.mean(0) / q_launch
         searching = frac_search > 0.5 if args.mode != "ref_cpp" else ms.mean(0) > 5e-3
         prof = dict(per=per, ms=ms.mean(0), frac_search=frac_search, wave_frac=sw.mean(0) / waves, searching=searching, q_launch=q_launch)
+
+    # ---------------- N > 1: what every rank spent where (HIP events around every phase of the sharded loop, on the stream)
+    rank_stats, roof_dist = None, None
+    if routed is not None:
+        cache_b = 48 if args.mode == "p2plane" else 32
+        mine_stat = {"rank": rank, "step_ms": elapsed_local / args.steps * 1e3, "map_points": len(mp), "scans": len(my_scans), "resumes": int(routed.resumes)}
+        grp = max(routed.mine.items(), key=lambda kv: len(kv[1][2])) if routed.mine else None
+        bases = [getattr(v[0], "icp", v[0]) for v in routed.mine.values()]       # TorchSharded wraps its api.Icp
+        for b_ in bases:
+            b_.profile_enable(True)
+        prof_steps = 2
+        for _ in range(prof_steps):
+            step()                                                                # every rank: the same collectives in the same order
+        torch.cuda.synchronize()
+        if grp is not None:
+            (a_, e_), (gicp, _, gids) = grp
+            base = getattr(gicp, "icp", gicp)
+            ms, sq, _sw = base.profile_launches()
+            per = max(len(ms) // prof_steps, 1)
+            ms = ms[:per * prof_steps].reshape(prof_steps, per).mean(0)
+            sq = sq[:per * prof_steps].reshape(prof_steps, per).mean(0)
+            is_sharded = (a_ != e_) or world == 1
+            owned = int(base.owned_counts().sum()) if is_sharded else n_scan * len(gids)
+            ph = {name: base.profile_phases(kind) for name, kind in (("reduce", api.PROF_REDUCE), ("collective", api.PROF_COLLECTIVE), ("solve", api.PROF_SOLVE),
+                                                                     ("shard_build", api.PROF_SHARD_BUILD))}
+            searching = sq / max(owned, 1) > 0.5
+            map_b = len(mp) * (32 if args.mode == "p2plane" else 16) + 4.0 * np.prod(mp.cell_size()[1])
+            comp = np.where(searching, owned * (12.0 + (cache_b if not args.no_nn_reuse else 0)) + map_b, owned * (12.0 + cache_b))
+            mine_stat.update({
+                "group": [int(a_), int(e_)], "group_scans": len(gids), "owned_queries_per_launch": owned,
+                "nn_us_per_launch": [round(float(v) * 1e3, 1) for v in ms], "nn_us_mean": float(ms.mean() * 1e3),
+                "queries_searching_frac_per_launch": [round(float(v) / max(owned, 1), 4) for v in sq],
+                "reduce_us_mean": float(ph["reduce"].mean() * 1e3) if len(ph["reduce"]) else None,
+                "collective_us_mean": float(ph["collective"].mean() * 1e3) if len(ph["collective"]) else None,
+                "collective_us_max": float(ph["collective"].max() * 1e3) if len(ph["collective"]) else None,
+                "solve_us_mean": float(ph["solve"].mean() * 1e3) if len(ph["solve"]) else None,
+                "shard_build_ms_mean": float(ph["shard_build"].mean()) if len(ph["shard_build"]) else None,
+                "compulsory_bytes_per_launch": float(comp.mean()),
+                "compulsory_gbs": float(comp.mean() / max(ms.mean() * 1e-3, 1e-12) / 1e9),
+            })
+        for b_ in bases:
+            b_.profile_enable(False)
+        all_stats = gather_stats(mine_stat)
+        if rank == 0:
+            def mm(key):
+                v = [st[key] for st in all_stats if st.get(key) is not None]
+                return {"min": min(v), "max": max(v), "mean": float(np.mean(v))} if v else None
+            rank_stats = {k: mm(k) for k in ("step_ms", "map_points", "scans", "owned_queries_per_launch", "nn_us_mean", "reduce_us_mean", "collective_us_mean",
+                                             "collective_us_max", "solve_us_mean", "shard_build_ms_mean", "resumes")}
+            rank_stats["per_rank"] = all_stats
+            rank_stats["note"] = ("HIP events on each rank's stream around every phase of the sharded loop of its largest group, 2 profiled steps after the timed "
+                                  "region; collective_us includes waiting for the slowest peer; nn_us_per_launch / queries_searching_frac_per_launch: the k_nn_red "
+                                  "launches of one alignment in order")
+            gbs = mm("compulsory_gbs")
+            if gbs is not None:
+                roof_dist = {"bound": "hbm", "achieved": gbs["mean"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs["mean"] / HBM_PEAK_GBS,
+                             "frac_min_rank": gbs["min"] / HBM_PEAK_GBS, "frac_max_rank": gbs["max"] / HBM_PEAK_GBS, "traffic": None,
+                             "achieved_from": "compulsory-traffic model per rank (owned queries x (12 B + neighbour cache) + the rank's map lines and cell table once per "
+                                              "searching launch) / that rank's mean k_nn_red launch time; mean over ranks",
+                             "kernel": "k_nn_red<SHARD>", "avg_launch_ms": mm("nn_us_mean")["mean"] * 1e-3,
+                             "queries_per_launch": mm("owned_queries_per_launch")}
+
+    # ---------------- N > 1, weak scaling: the same machine on `--batch` scans in ALL (strong scaling) for the record
+    strong = None
+    if routed is not None and world > 1 and args.scaling == "weak" and not args.no_extras:
+        keep_routed = routed
+        routed = make_routed(scans[:args.batch])
+        step()
+        barrier()
+        k_s = max(3, min(10, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(k_s):
+            step()
+        barrier()
+        ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=ddev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        strong = {"value": args.batch * k_s / float(ts.item()), "scans_in_flight": args.batch, "ms_per_step": float(ts.item()) / k_s * 1e3}
+        routed = keep_routed
 
     # ---------------- untimed extra legs: no-reuse throughput, upload-inclusive rate, single-scan latency
     extras = {}
@@ -495,12 +717,17 @@ def main():
                                       if args.scan_kind == "whole" else "scans routed to the slabs they touch, one-slab scans registered by one rank without a collective", comm_kind))
                    if sharded_run else "single GPU",
                    "hip_graph": (not args.no_graph) and not sharded_run,
+                   "collective": (coll_info or {}).get("kind"),
                    "shard_resumes": (routed.resumes if routed is not None else 0),
                    "routing_groups": ({"%d-%d" % k: len(v) for k, v in routed.groups.items()} if routed is not None else None)},
         "parity": {"max_translation_err_vs_truth_m": terr, "max_rotation_err_vs_truth_rad": rerr, "ok": bool(ok_truth)},
-        "roofline": roof,
+        "roofline": roof if roof is not None else roof_dist,
         "setup_s": setup_s,
     }
+    if sharded_run:
+        out["ranks"] = rank_stats
+        out["collective"] = coll_info
+        out["value_strong"] = strong
 
     # ---------------- CPU baseline: the oracle (port of the reference path), 1 thread, rank 0, N=1 -- and the parity gate
     if rank == 0 and world == 1 and not sharded_run and not args.no_cpu_baseline:
