@@ -473,7 +473,7 @@ def main():
     # ---------------- N > 1: what every rank spent where (HIP events around every phase of the sharded loop, on the stream)
     rank_stats, roof_dist = None, None
     if routed is not None:
-        cache_b = 48 if args.mode == "p2plane" else 32
+        cache_b = 32 if args.mode == "p2plane" else 20
         mine_stat = {"rank": rank, "step_ms": elapsed_local / args.steps * 1e3, "map_points": len(mp), "scans": len(my_scans), "resumes": int(routed.resumes)}
         grp = max(routed.mine.items(), key=lambda kv: len(kv[1][2])) if routed.mine else None
         bases = [getattr(v[0], "icp", v[0]) for v in routed.mine.values()]       # TorchSharded wraps its api.Icp
@@ -634,7 +634,7 @@ def main():
     roof = None
     if prof is not None:
         nn_ms = float(prof["ms"].mean())
-        cache_b = 48 if args.mode == "p2plane" else 32          # neighbour cache entry (3 / 2 float4 streams)
+        cache_b = 32 if args.mode == "p2plane" else 20          # neighbour cache entry: (neighbour, index) + (normal, E) / + E alone
         map_b = len(mp) * (32 if args.mode == "p2plane" else 16) + 4.0 * np.prod(mp.cell_size()[1])   # every point (+ normal) line and the cell table once
         sel_s, sel_v = prof["searching"], ~prof["searching"]
         if args.mode == "ref_cpp":
@@ -644,17 +644,27 @@ def main():
             comp_search = prof["q_launch"] * (12 + (cache_b if not args.no_nn_reuse else 0)) + map_b
             comp_verify = prof["q_launch"] * (12 + cache_b)
         comp = np.where(sel_s, comp_search, comp_verify)
-        traffic, traffic_src, valu = None, None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-            c = tj["config"]
-            if (world == 1 and c["batch"] == B and c["scan_points"] == n_scan and c["map_points"] == args.map_points and c["iters"] == iters
-                    and c["mode"] == args.mode and c.get("nn_reuse", True) == (not args.no_nn_reuse)):
-                traffic = tj["traffic_bytes_per_launch"]
-                traffic_src = "profiles/r02_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ by request size, separate passes)"
-                valu = tj.get("valu")
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_src, valu, traffic_note = None, None, None, None
+        src_hash = api.kernel_source_hash()
+
+        def load_traffic(name):
+            """profiles/<name> when it was taken on THIS build of the kernel and on this configuration, else None (+ why)."""
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                c = tj["config"]
+            except (OSError, KeyError, ValueError):
+                return None, "profiles/%s not found" % name
+            if tj.get("source_hash") != src_hash:
+                return None, "profiles/%s was measured on another build of the kernel (source hash %s, now %s)" % (name, tj.get("source_hash"), src_hash)
+            if not (world == 1 and c["batch"] == B and c["scan_points"] == n_scan and c["map_points"] == args.map_points and c["iters"] == iters and c["mode"] == args.mode):
+                return None, "profiles/%s is for another configuration" % name
+            return tj, None
+        tj, traffic_note = load_traffic("r03_traffic.json" if not args.no_nn_reuse else "r03_search_traffic.json")
+        if tj is not None and tj["config"].get("nn_reuse", True) == (not args.no_nn_reuse):
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_src = "profiles/%s (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ by request size, separate passes; source hash %s matches this build)" % (
+                "r03_traffic.json" if not args.no_nn_reuse else "r03_search_traffic.json", src_hash)
+            valu = tj.get("valu")
         bytes_launch = traffic if traffic is not None else float(comp.mean())
         achieved = bytes_launch / (nn_ms * 1e-3) / 1e9 if nn_ms > 0 else 0.0
 
@@ -668,7 +678,12 @@ def main():
                     "compulsory_frac_of_hbm_peak": float(comp[sel].mean() / (prof["ms"][sel].mean() * 1e-3) / 1e9 / HBM_PEAK_GBS)}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                "achieved_from": "PMC traffic" if traffic is not None else "compulsory-traffic model (every touched map line once + query / neighbour-cache streams)",
+                "achieved_from": "PMC traffic" if traffic is not None else
+                                 "compulsory-traffic model (every touched map line once + query / neighbour-cache streams) -- no counter file applies: %s" % traffic_note,
+                "kernel_source_hash": src_hash,
+                # the SURVEY §8(d) figure under its own name: 742 / 754 algorithmic bytes per query-iteration x queries per launch / average launch
+                # duration / peak.  It exceeds 1 because most searches are proven unnecessary and the rest are pruned and shared in L2
+                "sec8d_frac": prof["q_launch"] * a_nn / (nn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "kernel": "k_ref_nn" if args.mode == "ref_cpp" else "k_nn_red", "avg_launch_ms": nn_ms, "launches_per_alignment": int(prof["per"]),
                 "queries_per_launch": prof["q_launch"],
                 "phases": {"searching": phase(sel_s), "verifying": phase(sel_v)},

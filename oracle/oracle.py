@@ -401,3 +401,28 @@ def bf_align(src, tgt, prev_T, x_step=0.1, y_step=0.1, z_step=0.05, yaw_step=np.
                                C.byref(score), C.byref(idx), C.byref(ncand), _p(scores))
     return dict(found=bool(found), best_T=best.reshape(4, 4), best_score=score.value, index=idx.value,
                 n_candidates=ncand.value, scores=scores[:ncand.value].copy(), prev_T_after=prev.reshape(4, 4))
+
+
+# ------------------------------------------------------------------ Python twin: optimize_global_map_pose
+def map_builder_py(odom_positions, gps_imu_rows, max_poses=50, max_translation=0.5):
+    """map_T_global as the reference's Python MapBuilder computes it
+    (localization_python/localization_python/optimize_global_map_pose.py:21-32 leading poses under 0.5 m, :34-47 rows ->
+    pose[3:7] and UTM, :66-99 mean angles / mean position -> from_euler('xyz') -> inverse), restated with scipy's own
+    Rotation (the reference's dependency, importable here) and the oracle's C restatement of utm.from_latlon.
+    Raises ValueError like the reference when a row has anything but 6 columns' worth of angles."""
+    from scipy.spatial.transform import Rotation
+    odom = np.atleast_2d(np.asarray(odom_positions, dtype=np.float64))
+    rows = np.atleast_2d(np.asarray(gps_imu_rows, dtype=np.float64))
+    count = 0
+    for p in odom:
+        if np.linalg.norm(p) < max_translation:
+            count += 1
+        else:
+            break
+    rpy = [r[3:7] for r in rows]
+    t = [np.array([*utm_from_latlon(r[0], r[1])[:2], r[2]]) for r in rows]
+    n = min(count, len(rpy), max_poses)
+    G = np.eye(4)
+    G[:3, :3] = Rotation.from_euler('xyz', np.mean(rpy[:n], axis=0)).as_matrix()
+    G[:3, 3] = np.mean(t[:n], axis=0)
+    return np.linalg.inv(G), n

@@ -92,6 +92,17 @@ def load_library():
     return lib
 
 
+def kernel_source_hash():
+    """sha256[:16] of the sources the dominant kernel (k_nn_red / k_ref_nn) is compiled from.  profiles/*_traffic.json
+    carry the hash of the build their counters were taken on; bench.py only quotes them while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("sf_icp.hip", "sf_nn.hpp", "sf_order.hpp", "sf_common.hpp"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _check(rc):
     if rc != 0:
         raise SlamFusionError("libslamfusion error %d: %s" % (rc, load_library().sf_last_error().decode()))

@@ -49,8 +49,10 @@ struct IcpState {
     float step[12];
     int step_pending;
     int iterations, done, research, n_corr, n_research, flags, converged;
-    int n_points, pad_; // single-scan REF_CPP with the count in device memory: the count the alignment ran on (sf_icp_source_count)
+    int n_points; // single-scan REF_CPP with the count in device memory: the count the alignment ran on (sf_icp_source_count)
+    int cache_live; // launch list, O3D_P2P / P2PLANE: the scan's neighbour-cache entries have been written since the last (re)start
     double T_list[12]; // sharded path: the pose this rank's owned-query arrays were built at
+    double motion;     // launch list: upper bound on how far any point of the source batch has moved since the alignment began (sum over the pose updates)
 };
 
 struct IcpParams {
@@ -458,7 +460,8 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
     s.step_pending = 0;
     s.iterations = s.done = s.research = s.n_corr = s.n_research = s.flags = s.converged = 0;
     s.n_points = -1;
-    s.pad_ = 0;
+    s.cache_live = 0;
+    s.motion = 0.0;
     for (int i = 0; i < 12; ++i) s.T_list[i] = s.T[i];
     st[b] = s;
 }
@@ -466,11 +469,20 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
 // ------------------------------------------------------------------ fused transform + NN + accumulate
 // MODE 1: point-to-point record (17):  n, sum s[3], sum t[3], sum s t^T[9], sum d2
 // MODE 2: point-to-plane record (30):  n, sum r^2, JtJ upper[21], Jtr[6], sum d2
-// QPL queries per lane (grid.x = ceil(n / (256 * QPL)), grid.y = scans in the batch), one after the
+// Q queries per lane (grid.x = ceil(n / (256 * Q)), grid.y = scans in the batch), one after the
 // other: neighbour (reuse certificate or search), then the contributions of the lane's pairs are
-// added and go through ONE wave reduction.  Measured: QPL = 2 (half the reductions and slab rows,
-// 87 instead of 80 VGPR) is within 1 % of QPL = 1 at 1, 8 and 32 scans in flight -- the simpler one stays.
-constexpr int QPL = 1;
+// added and go through ONE wave reduction.  Q is part of the summation order, so it is a function of
+// the scan size alone (sf_icp::qpl): scans up to 131 072 points -- everything the single-launch
+// kernels can take, whose rows are 256 points -- use Q = 1 and match them bit for bit; larger scans
+// use Q = SF_WIDE_QPL.  Round 1 measured Q = 2 within 1 % of Q = 1 when every query searched; since
+// the neighbour reuse most launches of an alignment only verify, and a verifying wave is
+// vector-issue bound with the record reduction (~160 of its ~390 instructions) the largest item:
+// Q = 2 halves that per query.
+#ifndef SF_WIDE_QPL
+#define SF_WIDE_QPL 2
+#endif
+constexpr int64_t WIDE_SCAN_POINTS = 131072;
+constexpr int VERIFY_FROM_SEARCH = 4; // wide scans: from the fifth launch of an alignment on a wave first tries to verify all its queries at once
 #ifndef NN_RED_WAVES
 #define NN_RED_WAVES 4
 #endif
@@ -482,17 +494,60 @@ struct LanePair {
     float4 tn;         // the neighbour's normal (MODE 2)
     bool ok;
 };
+struct QueryIn;
 
-// Neighbour reuse with an exactness certificate.  The last full search of this query (at position
-// c0.xyz) found neighbour c1 = (point, index) and proved every OTHER map point at least c0.w
-// away.  The query has moved by delta since; if |q - p| < c0.w - delta (triangle inequality, with
-// a rounding margin) no other point can be nearer, so the search would return the same
-// neighbour -- it is skipped, the result is bit-identical.  ICP steps shrink geometrically, so
-// after the first few iterations whole waves certify (and then read their pair -- neighbour and
-// normal -- from three coalesced float4 streams instead of gathering it); a wave with any lane
-// left runs the search for just those lanes.
+// Neighbour reuse with an exactness certificate.  The last full search of this query found neighbour c1 = (point,
+// index) and proved every OTHER map point at least D away from where the query was then.  Since then the query has
+// moved by at most M_now - M_then, where M (IcpState::motion) adds up, over the pose updates of the alignment, the
+// largest displacement any point of the source batch's bounding box can have had (an affine map moves a box's corners
+// the most).  If |q - p| < D - (M_now - M_then) (triangle inequality, with rounding margins: both positions are
+// float32 roundings of float64 products) no other point can be nearer, so the search would return the same
+// neighbour -- it is skipped, the result is bit-identical.  What is kept per query is E = D + M_then, ONE float
+// (in the w of the cached normal; its own array in MODE 1), not the position of the last search: a verifying wave
+// streams 12 B of scan point + 16 B neighbour + 16 B normal-and-E = 44 B per query (round 2: 60).  ICP steps shrink
+// geometrically, so after the first few iterations whole waves certify; a wave with any lane left runs the search
+// for just those lanes.  E <= 0 marks an entry without a search behind it.
 // Returns whether the query must search; hit / tn = the certified pair (or "none yet"), seed = where a search may start.
-__device__ __forceinline__ bool reuse_certificate(bool valid, float qx, float qy, float qz, float thr, const float4 &c0, const float4 &c1, const float4 &c2, sf::NNHit &hit,
+__device__ __forceinline__ bool reuse_certificate(bool valid, float qx, float qy, float qz, float thr, float m_now, float e, const float4 &c1, const float4 &c2, sf::NNHit &hit,
+                                                  float4 &tn, sf::NNHit &seed)
+{
+    hit.d2 = thr;
+    hit.j = -1;
+    hit.px = hit.py = hit.pz = 0.0f;
+    hit.lb2 = 0.0f;
+    tn = make_float4(0.f, 0.f, 0.f, 0.f); // the neighbour's normal (MODE 2)
+    bool need = valid;
+    seed = sf::NNHit{0.0f, -1, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (valid) {
+        if (e > 0.0f) {
+            const int32_t jc = __float_as_int(c1.w);
+            // e - m_now bounds D - |q - q_then| from below; the float32 roundings of q and q_then are charged here
+            const float reach = e - m_now * 1.000002f - (fabsf(qx) + fabsf(qy) + fabsf(qz) + 1.0f) * 1.3e-7f - 1.0e-6f;
+            if (jc >= 0) {
+                const float d2n = sf::l2_simple(qx, qy, qz, c1.x, c1.y, c1.z);
+                if (sqrtf(d2n) * 1.0001f + 1.0e-6f < reach) {
+                    need = false;
+                    if (d2n < thr) {
+                        hit.d2 = d2n; hit.j = jc; hit.px = c1.x; hit.py = c1.y; hit.pz = c1.z;
+                        tn = c2;
+                    }
+                } else {
+                    // not certified: the search still starts from the old neighbour's current distance instead of the
+                    // acceptance threshold (exact all the same -- sf_nn.hpp -- and ranges beyond it are pruned unvisited;
+                    // measured: 2 % on the second to fourth launch of an alignment)
+                    seed.d2 = d2n; seed.j = jc; seed.px = c1.x; seed.py = c1.y; seed.pz = c1.z;
+                }
+            } else if (sqrtf(thr) * 1.0001f + 1.0e-6f < reach) {
+                need = false; // still nothing within the acceptance radius
+            }
+        }
+    }
+    return need;
+}
+
+// The same certificate with the position of the last search kept per query (c0 = (position, D)): the single-launch
+// kernels hold their cache in registers, where the position costs no traffic and the bound is the query's own motion.
+__device__ __forceinline__ bool reuse_certificate_pos(bool valid, float qx, float qy, float qz, float thr, const float4 &c0, const float4 &c1, const float4 &c2, sf::NNHit &hit,
                                                   float4 &tn, sf::NNHit &seed)
 {
     hit.d2 = thr;
@@ -529,38 +584,76 @@ __device__ __forceinline__ bool reuse_certificate(bool valid, float qx, float qy
     return need;
 }
 
+// what a lane reads of its query: the scan point under the current pose (float64 products, rounded to the float32 the
+// search works in), whether this rank owns it, and -- once the scan's cache entries are written -- its cached pair
+struct QueryIn {
+    double sx, sy, sz;
+    float qx, qy, qz;
+    float4 c1, c2; // (neighbour, index), (neighbour's normal, E)   [MODE 1: E alone, from its own array]
+    float e;
+    size_t o;
+    bool valid;
+};
+
+// no side effects: the loads of several queries of a lane can all be in flight together
+template <int MODE, bool SHARD>
+__device__ __forceinline__ QueryIn query_in(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n, int b, const IcpState *S, float xlo,
+                                            float xhi, const uint32_t *__restrict__ own_off, const float4 *__restrict__ qcache, int64_t cache_n, bool cache_live, int slot,
+                                            int n_live)
+{
+    QueryIn q;
+    q.sx = q.sy = q.sz = 0.0;
+    q.qx = q.qy = q.qz = 0.0f;
+    q.c1 = q.c2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    q.e = 0.0f;
+    q.o = 0;
+    q.valid = false;
+    if (slot < n_live) {
+        const size_t o = SHARD ? (size_t)own_off[b] + (size_t)slot : (size_t)b * n + (size_t)slot;
+        q.o = o;
+        if (cache_live) {
+            q.c1 = qcache[o];
+            if (MODE == 2) { q.c2 = qcache[(size_t)cache_n + o]; q.e = q.c2.w; }
+            else q.e = reinterpret_cast<const float *>(qcache + (size_t)cache_n)[o]; // MODE 1: E has an array of its own
+        }
+        const double x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
+        q.sx = S->T[0] * x0 + S->T[1] * y0 + S->T[2] * z0 + S->T[3];
+        q.sy = S->T[4] * x0 + S->T[5] * y0 + S->T[6] * z0 + S->T[7];
+        q.sz = S->T[8] * x0 + S->T[9] * y0 + S->T[10] * z0 + S->T[11];
+        q.qx = (float)q.sx; q.qy = (float)q.sy; q.qz = (float)q.sz;
+        q.valid = !SHARD || (q.qx >= xlo && q.qx < xhi);
+    }
+    return q;
+}
+
+__device__ __forceinline__ LanePair make_pair(const QueryIn &q, const sf::NNHit &hit, const float4 &tn)
+{
+    LanePair P;
+    P.sx = q.sx; P.sy = q.sy; P.sz = q.sz;
+    P.px = hit.px; P.py = hit.py; P.pz = hit.pz;
+    P.tn = tn;
+    P.ok = hit.j >= 0;
+    return P;
+}
+
 template <int MODE, bool WINDOW, bool SHARD>
 __device__ __forceinline__ LanePair nn_pair(const SfGrid &g, const SfWindow &w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                             int n, int b, const IcpState *S, float thr, float xlo, float xhi, const uint32_t *__restrict__ own_off,
                                             float4 *__restrict__ qcache, int64_t cache_n, int slot, int n_live, sf::WaveNN *ws, uint32_t *__restrict__ stats)
 {
-    double sx = 0, sy = 0, sz = 0;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    bool valid = false;
-    size_t o = 0;
-    // once the alignment has searched (every entry is then either written or still zero from the
-    // reset) the three cache streams are requested together with the scan point: one round trip
-    // for a verifying wave instead of four dependent ones
-    const bool cache_live = qcache != nullptr && S->n_research > 0;
-    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0;
-    if (slot < n_live) {
-        o = SHARD ? (size_t)own_off[b] + (size_t)slot : (size_t)b * n + (size_t)slot;
-        if (cache_live) {
-            c0 = qcache[o];
-            c1 = qcache[(size_t)cache_n + o];
-            if (MODE == 2) c2 = qcache[2 * (size_t)cache_n + o];
-        }
-        const double x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
-        sx = S->T[0] * x0 + S->T[1] * y0 + S->T[2] * z0 + S->T[3];
-        sy = S->T[4] * x0 + S->T[5] * y0 + S->T[6] * z0 + S->T[7];
-        sz = S->T[8] * x0 + S->T[9] * y0 + S->T[10] * z0 + S->T[11];
-        qx = (float)sx; qy = (float)sy; qz = (float)sz;
-        valid = !SHARD || (qx >= xlo && qx < xhi);
-    }
+    // once the scan's entries have been written (every lane writes its entry in the first launch after a (re)start,
+    // searched or not, so the cache is never reset) the cache streams are requested together with the scan point: one
+    // round trip for a verifying wave instead of dependent ones
+    const bool cache_live = qcache != nullptr && S->cache_live != 0;
+    const QueryIn q = query_in<MODE, SHARD>(X0x, X0y, X0z, n, b, S, xlo, xhi, own_off, qcache, cache_n, cache_live, slot, n_live);
+    const float qx = q.qx, qy = q.qy, qz = q.qz;
+    const size_t o = q.o;
+    float *ecache = reinterpret_cast<float *>(qcache + (size_t)cache_n);
+    const float m_now = (float)S->motion;
     sf::NNHit hit;
     float4 tn;
     sf::NNHit seed;
-    const bool need = reuse_certificate(valid, qx, qy, qz, thr, c0, c1, c2, hit, tn, seed);
+    const bool need = reuse_certificate(q.valid, qx, qy, qz, thr, m_now, q.e, q.c1, q.c2, hit, tn, seed);
     // every lane takes part in the search (lanes without a query still execute other lanes' tasks)
     const unsigned long long need_mask = __ballot(need);
     if (stats && (threadIdx.x & 63) == 0 && need_mask) { // profiling only (integer counters: order independent); sharded: one address would serialise 100 k waves
@@ -575,21 +668,23 @@ __device__ __forceinline__ LanePair nn_pair(const SfGrid &g, const SfWindow &w, 
             // only the winner's normal is fetched after the search; its coordinates come in registers
             if (MODE == 2 && h.j >= 0) tn = g.nrm[h.j];
             if (qcache) {
-                qcache[o] = make_float4(qx, qy, qz, sqrtf(h.lb2));
-                qcache[(size_t)cache_n + o] = make_float4(h.px, h.py, h.pz, __int_as_float(h.j));
-                if (MODE == 2) qcache[2 * (size_t)cache_n + o] = tn;
+                // E = D + M, rounded down: D = sqrt(lb2) is the proven distance of every other point
+                const float en = fmaxf(sqrtf(h.lb2) * 0.9999f + m_now * 0.999998f - 1.0e-6f, 1.0e-30f);
+                qcache[o] = make_float4(h.px, h.py, h.pz, __int_as_float(h.j));
+                if (MODE == 2) qcache[(size_t)cache_n + o] = make_float4(tn.x, tn.y, tn.z, en);
+                else ecache[o] = en;
             }
         }
     }
-    LanePair P;
-    P.sx = sx; P.sy = sy; P.sz = sz;
-    P.px = hit.px; P.py = hit.py; P.pz = hit.pz;
-    P.tn = tn;
-    P.ok = hit.j >= 0;
-    return P;
+    if (qcache && !cache_live && !need && slot < n_live) { // first launch after a (re)start: a lane that did not search (outside the slab) leaves "no search behind it"
+        if (MODE == 2) qcache[(size_t)cache_n + o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else ecache[o] = 0.0f;
+    }
+    return make_pair(q, hit, tn);
 }
 
-// lanes without a correspondence contribute exact zeros: e = 0 and n = 0 zero every product
+// lanes without a correspondence contribute exact zeros: their point, neighbour and normal are zeroed once (a non-finite
+// dead query must not turn 0 * s into NaN), after which every term is plain arithmetic on zeros
 struct PairTerms { double wgt, ux, uy, uz, tx, ty, tz, ex, ey, ez, d2, r; double J[6]; };
 template <int MODE>
 __device__ __forceinline__ PairTerms pair_terms(const LanePair &P)
@@ -597,12 +692,12 @@ __device__ __forceinline__ PairTerms pair_terms(const LanePair &P)
     PairTerms t;
     const bool ok = P.ok;
     t.wgt = ok ? 1.0 : 0.0;
-    t.tx = ok ? (double)P.px : 0.0; t.ty = ok ? (double)P.py : 0.0; t.tz = ok ? (double)P.pz : 0.0;
-    t.ex = ok ? P.sx - t.tx : 0.0; t.ey = ok ? P.sy - t.ty : 0.0; t.ez = ok ? P.sz - t.tz : 0.0;
+    t.ux = ok ? P.sx : 0.0; t.uy = ok ? P.sy : 0.0; t.uz = ok ? P.sz : 0.0;
+    t.tx = (double)(ok ? P.px : 0.0f); t.ty = (double)(ok ? P.py : 0.0f); t.tz = (double)(ok ? P.pz : 0.0f);
+    t.ex = t.ux - t.tx; t.ey = t.uy - t.ty; t.ez = t.uz - t.tz;
     t.d2 = t.ex * t.ex + t.ey * t.ey + t.ez * t.ez;
-    t.ux = ok ? P.sx : 0.0; t.uy = ok ? P.sy : 0.0; t.uz = ok ? P.sz : 0.0; // a non-finite dead query must not turn 0 * s into NaN
     if (MODE == 2) {
-        const double nx = P.tn.x, ny = P.tn.y, nz = P.tn.z; // zero for dead lanes -> J = 0, r = 0
+        const double nx = (double)(ok ? P.tn.x : 0.0f), ny = (double)(ok ? P.tn.y : 0.0f), nz = (double)(ok ? P.tn.z : 0.0f);
         t.r = t.ex * nx + t.ey * ny + t.ez * nz;
         t.J[0] = t.uy * nz - t.uz * ny; t.J[1] = t.uz * nx - t.ux * nz; t.J[2] = t.ux * ny - t.uy * nx;
         t.J[3] = nx; t.J[4] = ny; t.J[5] = nz;
@@ -651,7 +746,7 @@ __device__ __forceinline__ void add_half(const PairTerms &t, int h, double (&v)[
     }
 }
 
-template <int MODE, bool WINDOW, bool SHARD>
+template <int MODE, bool WINDOW, bool SHARD, int Q>
 __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                                 int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks,
                                                 const uint32_t *__restrict__ own_off, float4 *__restrict__ qcache, int64_t cache_n, uint32_t *__restrict__ stats)
@@ -659,7 +754,7 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red(SfGrid g, SfWindow
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in launch order, so
     // linear id L runs on XCD L % 8.  Each XCD sweeps its own CONTIGUOUS eighth of the chunks
-    // (chunk = 256 * QPL consecutive queries of a scan), all scans of the batch adjacent in time:
+    // (chunk = 256 * Q consecutive queries of a scan), all scans of the batch adjacent in time:
     // with cell-ordered queries, chunk c of every scan covers about the same stretch of the map (to
     // within a chunk or so), so neighbouring chunks must meet in the same L2.  grid.x is padded
     // to a multiple of 8.
@@ -674,16 +769,39 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red(SfGrid g, SfWindow
     // the margin at the pose the arrays were built at, cell-ordered, scan b at [own_off[b], own_off[b+1]));
     // the exact slab predicate is still applied per lane
     const int n_live = SHARD ? (int)(own_off[b + 1] - own_off[b]) : n;
-    if (SHARD && bx * (BLK * QPL) >= n_live) return; // k_reduce_only reads only the rows that exist
+    if (SHARD && bx * (BLK * Q) >= n_live) return; // k_reduce_only reads only the rows that exist
     __shared__ sf::WaveNN nn_ws[BLK / 64];
     __shared__ double stage[BLK / 64][32];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    PairTerms T[QPL];
+    // the pairs are kept, not their terms (13 against 36 registers per query across the next search); the terms are
+    // formed once per half below
+    LanePair P[Q];
+    // Q > 1, from the launch on in which most waves only verify: the loads of ALL the lane's queries go out together (one
+    // round trip per wave, Q times the bytes in flight) and, if every lane of the wave certifies every one of its
+    // queries, the pairs come straight from them.  A wave with anything left to search drops what it loaded and takes the
+    // queries one after the other as always -- the same pairs either way, so which path a wave takes changes no bit.
+    bool fast = false;
+    if (Q > 1 && qcache != nullptr && S->cache_live != 0 && S->n_research >= VERIFY_FROM_SEARCH) {
+        const float m_now = (float)S->motion;
+        bool any_need = false;
 #pragma unroll
-    for (int u = 0; u < QPL; ++u) {
-        const int slot = bx * (BLK * QPL) + u * BLK + (int)threadIdx.x;
-        const LanePair P = nn_pair<MODE, WINDOW, SHARD>(g, w, X0x, X0y, X0z, n, b, S, thr, xlo, xhi, own_off, qcache, cache_n, slot, n_live, &nn_ws[wv], stats);
-        T[u] = pair_terms<MODE>(P);
+        for (int u = 0; u < Q; ++u) {
+            const int slot = bx * (BLK * Q) + u * BLK + (int)threadIdx.x;
+            const QueryIn q = query_in<MODE, SHARD>(X0x, X0y, X0z, n, b, S, xlo, xhi, own_off, qcache, cache_n, true, slot, n_live);
+            sf::NNHit hit, seed;
+            float4 tn;
+            any_need = reuse_certificate(q.valid, q.qx, q.qy, q.qz, thr, m_now, q.e, q.c1, q.c2, hit, tn, seed) || any_need;
+            P[u] = make_pair(q, hit, tn);
+        }
+        fast = __ballot(any_need) == 0ull;
+    }
+    if (!fast) {
+        asm volatile("" ::: "memory"); // nothing loaded above stays live across the searches below
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+            const int slot = bx * (BLK * Q) + u * BLK + (int)threadIdx.x;
+            P[u] = nn_pair<MODE, WINDOW, SHARD>(g, w, X0x, X0y, X0z, n, b, S, thr, xlo, xhi, own_off, qcache, cache_n, slot, n_live, &nn_ws[wv], stats);
+        }
     }
     // the lane's pairs added, reduced over the wave in two halves of 16 values (keeps the live
     // registers low enough for 4+ waves per SIMD), staged per wave in LDS
@@ -693,7 +811,10 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red(SfGrid g, SfWindow
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = 0.0;
 #pragma unroll
-        for (int u = 0; u < QPL; ++u) add_half<MODE>(T[u], h, v);
+        for (int u = 0; u < Q; ++u) {
+            const PairTerms t = pair_terms<MODE>(P[u]);
+            add_half<MODE>(t, h, v);
+        }
         if (MODE == 1 && h == 1) {
             const double t1 = wave_reduce_1(v[0]);
             if (lane == 0) stage[wv][16] = t1;
@@ -906,6 +1027,7 @@ __global__ void k_own_mark(IcpState *__restrict__ st, int batch)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch || st[b].done) return;
     for (int i = 0; i < 12; ++i) st[b].T_list[i] = st[b].T[i];
+    st[b].cache_live = 0; // the compact indices of this scan have changed: its cache entries mean nothing until rewritten
 }
 
 // after a pose update: has any point of the scan's bounding box come close to the margin away from
@@ -927,6 +1049,25 @@ __device__ __forceinline__ void own_check_motion(IcpState *S, const ScanBox &box
         S->flags |= SF_ICP_FLAG_SHARD_STALE;
         S->done = 1;
     }
+}
+
+// after a pose update of the launch list: IcpState::motion grows by the largest displacement the update gave any point of
+// the source batch's bounding box (rounded up), and the scan's cache entries count as written (reuse_certificate)
+__device__ __forceinline__ void track_motion(IcpState *S, const double *To, const ScanBox &box)
+{
+    double worst = 0.0;
+    for (int c = 0; c < 8; ++c) {
+        const double x = (c & 1) ? box.hi[0] : box.lo[0], y = (c & 2) ? box.hi[1] : box.lo[1], z = (c & 4) ? box.hi[2] : box.lo[2];
+        double d2 = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            const double d = (S->T[4 * r] - To[4 * r]) * x + (S->T[4 * r + 1] - To[4 * r + 1]) * y + (S->T[4 * r + 2] - To[4 * r + 2]) * z + (S->T[4 * r + 3] - To[4 * r + 3]);
+            d2 += d * d;
+        }
+        worst = d2 > worst ? d2 : worst;
+    }
+    const double step = sqrt(worst) * 1.000001 + 1.0e-9;
+    S->motion = (step == step) ? S->motion + step : 1.0e30; // a non-finite pose: nothing certifies any more
+    S->cache_live = 1;
 }
 
 // ------------------------------------------------------------------ solves (thread 0 of the scan's workgroup)
@@ -995,7 +1136,8 @@ __device__ __forceinline__ void solve_plane(IcpState *S, const double *rec, int 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(RBLK) void k_reduce_solve(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, int n_src, int k, int K)
+__global__ __launch_bounds__(RBLK) void k_reduce_solve(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, int n_src, int k, int K,
+                                                       const ScanBox *__restrict__ boxp)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x;
@@ -1005,15 +1147,19 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve(IcpState *__restrict__ st
     reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, nblocks, rec);
     if (threadIdx.x == 0) {
         for (int c = 0; c < NREC; ++c) S->rec[c] = rec[c];
+        double To[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) To[i] = S->T[i];
         if (MODE == 1) solve_o3d(S, rec, n_src, k, K);
         else solve_plane(S, rec, n_src, K);
+        track_motion(S, To, *boxp);
     }
 }
 
 // multi-GPU split: reduce into the exchange buffer, all-reduce outside, then solve
 template <int MODE>
 __global__ __launch_bounds__(RBLK) void k_reduce_only(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, double *__restrict__ xchg,
-                                                      const uint32_t *__restrict__ own_off)
+                                                      const uint32_t *__restrict__ own_off, int qpl)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x;
@@ -1022,7 +1168,7 @@ __global__ __launch_bounds__(RBLK) void k_reduce_only(IcpState *__restrict__ st,
         if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = 0.0;
         return;
     }
-    const int rows = own_off ? (int)((own_off[b + 1] - own_off[b] + BLK * QPL - 1) / (BLK * QPL)) : nblocks; // sharded: workgroups beyond the owned queries wrote nothing
+    const int rows = own_off ? (int)((own_off[b + 1] - own_off[b] + BLK * qpl - 1) / (BLK * qpl)) : nblocks; // sharded: workgroups beyond the owned queries wrote nothing
     reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, rows, rec);
     if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = rec[threadIdx.x];
 }
@@ -1040,8 +1186,12 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
     for (int c = 0; c < REC_STRIDE; ++c) rec[c] = c < NREC ? xchg[(size_t)b * REC_STRIDE + c] : 0.0;
 #pragma unroll
     for (int c = 0; c < NREC; ++c) S->rec[c] = rec[c];
+    double To[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) To[i] = S->T[i];
     if (MODE == 1) solve_o3d(S, rec, n_src, 0, K);
     else solve_plane(S, rec, n_src, K);
+    track_motion(S, To, *boxp);
     if (margin > 0.0f && !S->done) own_check_motion(S, *boxp, margin); // sharded path only (the box of the source batch, computed on the device)
 }
 
@@ -1510,7 +1660,7 @@ __global__ __launch_bounds__(BLK) void k_icp_fused(SfGrid g, SfWindow w, const f
         sf::NNHit seed;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool live = REUSE && S.n_research > 0;
-        const bool need = reuse_certificate(have, qx, qy, qz, thr, live ? c0 : z4, live ? c1 : z4, live ? c2 : z4, hit, tn, seed);
+        const bool need = reuse_certificate_pos(have, qx, qy, qz, thr, live ? c0 : z4, live ? c1 : z4, live ? c2 : z4, hit, tn, seed);
         if (__ballot(need) != 0ull) {
             const sf::NNHit h = sf::nn_search_wave<WINDOW>(g, w, need, qx, qy, qz, thr, &nn_ws[wv], seed);
             if (need) {
@@ -1593,7 +1743,7 @@ struct sf_icp {
     // source
     sf::DevBuf X0, X;        // SoA: x[B*n], y[B*n], z[B*n]
     sf::DevBuf X0r;          // the same points as float4 records (gather source of the query ordering)
-    sf::DevBuf qcache;       // neighbour reuse, three float4 arrays of cache_n entries: (query position at its last full search, runner-up bound), (neighbour, its index), (neighbour's normal)
+    sf::DevBuf qcache;       // neighbour reuse, two float4 arrays of cache_n entries: (neighbour, its index), (neighbour's normal, E) -- O3D_P2P: the second array holds E alone, as floats
     int64_t cache_n = 0;
     bool reuse = true;       // sf_icp_set_nn_reuse
     sf::DevBuf Xq, qkeys, qkeys2, qidx, qidx2; // cell-ordered copy of X0 and the sort's buffers
@@ -1623,7 +1773,8 @@ struct sf_icp {
     void *xchg = nullptr;
     int64_t xchg_bytes = 0;
     int nblocks = 0;         // workgroups of 256 points covering a scan (REF_CPP kernels, owned-query compaction)
-    int nblocks_nn = 0;      // k_nn_red workgroups per scan = slab rows (256 * QPL queries each)
+    int nblocks_nn = 0;      // k_nn_red workgroups per scan = slab rows (256 * qpl queries each)
+    int qpl = 1;             // queries per lane of k_nn_red: 1 up to WIDE_SCAN_POINTS points per scan, SF_WIDE_QPL beyond (part of the summation order)
     std::vector<IcpState> h_state;
     // sharding
     bool shard = false;
@@ -1707,9 +1858,10 @@ int reuse_reset(sf_icp *icp, int64_t count)
 {
     if (!icp->reuse) return SF_OK;
     const size_t c = (size_t)std::max<int64_t>(count, 1);
-    SF_TRY(icp->qcache.reserve(sizeof(float4) * 3 * c));
+    // nothing is cleared: a scan's entries count only once IcpState::cache_live says they have been written (every lane
+    // writes its entry in the first launch after a start or a rebuild of the owned arrays)
+    SF_TRY(icp->qcache.reserve(sizeof(float4) * 2 * c));
     icp->cache_n = (int64_t)c;
-    SF_HIP(hipMemsetAsync(icp->qcache.p, 0, sizeof(float4) * c, icp->ctx->stream)); // the bounds (first array) only
     return SF_OK;
 }
 
@@ -1774,7 +1926,8 @@ int icp_alloc(sf_icp *icp, int64_t n, int batch)
     // device memory), so the launch geometry -- and with it a captured graph -- is shared by scans of similar size
     icp->n_cap = batch == 1 ? sf::div_up(std::max<int64_t>(n, 1), 4096) * 4096 : n;
     icp->nblocks = (int)std::max<int64_t>(1, sf::div_up(icp->n_cap, BLK));
-    icp->nblocks_nn = (int)std::max<int64_t>(1, sf::div_up(n, BLK * QPL));
+    icp->qpl = n > WIDE_SCAN_POINTS ? SF_WIDE_QPL : 1;
+    icp->nblocks_nn = (int)std::max<int64_t>(1, sf::div_up(n, BLK * icp->qpl));
     SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)REC_STRIDE * (size_t)icp->nblocks * (size_t)batch));
     SF_TRY(icp->xchg_own.reserve(sizeof(double) * REC_STRIDE * (size_t)batch));
     if (icp->batch != batch || icp->inits.size() != (size_t)batch * 16) {
@@ -1878,13 +2031,19 @@ void launch_nn_red(sf_icp *icp, bool sharded = false)
     uint32_t *stats = nullptr;
     if (icp->profiling && icp->nn_stats.p && icp->nn_stats_used < sf_icp::NN_STATS_CAP) stats = icp->nn_stats.as<uint32_t>() + 2 * NN_STATS_SHARDS * icp->nn_stats_used++;
     const bool win = m->window.kind != 0;
-#define SF_LAUNCH_NNRED(W, S)                                                                                                                                    \
-    hipLaunchKernelGGL((k_nn_red<MODE, W, S>), grid, blk, 0, s, m->grid, m->window, x, y, z, (int)icp->n, st, thr, icp->xlo, icp->xhi, part, nb, \
+#define SF_LAUNCH_NNRED_Q(W, S, QQ)                                                                                                                              \
+    hipLaunchKernelGGL((k_nn_red<MODE, W, S, QQ>), grid, blk, 0, s, m->grid, m->window, x, y, z, (int)icp->n, st, thr, icp->xlo, icp->xhi, part, nb, \
                        icp->own_off.as<uint32_t>(), icp->reuse ? icp->qcache.as<float4>() : nullptr, icp->cache_n, stats)
+#define SF_LAUNCH_NNRED(W, S)                                  \
+    do {                                                       \
+        if (icp->qpl == 1) SF_LAUNCH_NNRED_Q(W, S, 1);         \
+        else SF_LAUNCH_NNRED_Q(W, S, SF_WIDE_QPL);             \
+    } while (0)
     if (win && sharded) SF_LAUNCH_NNRED(true, true);
     else if (win) SF_LAUNCH_NNRED(true, false);
     else if (sharded) SF_LAUNCH_NNRED(false, true);
     else SF_LAUNCH_NNRED(false, false);
+#undef SF_LAUNCH_NNRED_Q
 #undef SF_LAUNCH_NNRED
 }
 
@@ -1935,12 +2094,12 @@ int enqueue_align(sf_icp *icp, int mode)
     if (mode == SF_ICP_O3D_P2P) {
         for (int k = 0; k <= K; ++k) {
             launch_nn_red<1>(icp);
-            hipLaunchKernelGGL(k_reduce_solve<1>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K);
+            hipLaunchKernelGGL(k_reduce_solve<1>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K, icp->d_box.as<ScanBox>());
         }
     } else if (mode == SF_ICP_P2PLANE) {
         for (int k = 0; k < K; ++k) {
             launch_nn_red<2>(icp);
-            hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K);
+            hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K, icp->d_box.as<ScanBox>());
         }
     } else {
         SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(icp->plane, 1)));
@@ -2011,7 +2170,8 @@ int fused_capacity(sf_icp *icp, int mode)
 bool fused_eligible(sf_icp *icp, int mode)
 {
     const int64_t rows = mode == SF_ICP_REF_CPP ? icp->nblocks : icp->nblocks_nn;
-    return icp->fused && !icp->profiling && !icp->shard && rows * icp->batch <= (int64_t)fused_capacity(icp, mode);
+    // the single-launch kernels keep one point per lane (rows of 256): wide scans (qpl > 1) are not theirs
+    return icp->fused && !icp->profiling && !icp->shard && (mode == SF_ICP_REF_CPP || icp->qpl == 1) && rows * icp->batch <= (int64_t)fused_capacity(icp, mode);
 }
 
 template <int MODE>
@@ -2500,7 +2660,7 @@ int shard_build(sf_icp *icp, bool resume)
     }
     const int64_t own = (int64_t)icp->h_own[(size_t)B];
     icp->own_total = own;
-    icp->own_nblocks = (int)std::max<int64_t>(1, sf::div_up((int64_t)maxc, BLK * QPL));
+    icp->own_nblocks = (int)std::max<int64_t>(1, sf::div_up((int64_t)maxc, BLK * icp->qpl));
     SF_HIP(hipMemcpyAsync(icp->own_off.p, icp->h_own.data(), sizeof(uint32_t) * (size_t)(B + 1), hipMemcpyHostToDevice, s));
     const size_t cap = (size_t)std::max<int64_t>(own, 1);
     SF_TRY(icp->own_idx.reserve(sizeof(uint32_t) * cap));
@@ -2544,11 +2704,11 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
     if (mode == SF_ICP_O3D_P2P) {
         launch_nn_red<1>(icp, icp->shard);
         ProfScope ps(icp, SF_PROF_REDUCE);
-        hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off);
+        hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl);
     } else {
         launch_nn_red<2>(icp, icp->shard);
         ProfScope ps(icp, SF_PROF_REDUCE);
-        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off);
+        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl);
     }
     SF_HIP(hipGetLastError());
     return SF_OK;

@@ -3,7 +3,11 @@
 kernel by request size, and its vector-issue figures.
 usage: make_traffic_json.py profiles/r02 <scans in flight> <mode> <iters> <reuse|noreuse>"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from slam_sensor_fusion_amd.api import kernel_source_hash  # noqa: E402
 
 prefix = sys.argv[1]
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
@@ -40,6 +44,7 @@ except (OSError, KeyError):
 out = {
     "kernel": key.split(" grid=")[0],
     "config": {"scan_points": 200000, "map_points": 10000000, "batch": batch, "iters": iters, "mode": mode, "nn_reuse": reuse},
+    "source_hash": kernel_source_hash(),
     "queries_per_launch": q,
     "read_requests_per_launch": {"32B": n32, "64B": n64, "128B": n128, "all": nall},
     "read_bytes_per_launch": read_b,
