@@ -250,6 +250,12 @@ int sf_icp_graph_counts(sf_icp *icp, int64_t *captures, int64_t *launches);
  * sf_icp_fused_count: how many alignments have taken the single-launch form since creation. */
 int sf_icp_set_fused(sf_icp *icp, int on);
 int sf_icp_fused_count(sf_icp *icp, int64_t *launches);
+/* Residency of a single-launch grid is kept by a per-device ledger of the grids in flight (all contexts of the process);
+ * an alignment that does not fit takes the launch list.  Should a grid barrier still give up (another PROCESS holding the
+ * compute units), the alignment is redone through the launch list inside sf_icp_fetch_results and the object stays on
+ * the launch list: sf_icp_fused_redone counts how often that happened. */
+int sf_icp_fused_redone(sf_icp *icp, int64_t *redone);
+int sf_icp_test_inject_barrier_timeout(sf_icp *icp); /* test hook: treat the next single-launch alignment as timed out (exercises the redo) */
 /* Order in which the points of a scan are walked by O3D_P2P / P2PLANE.  The correspondences and
  * every per-point term are independent of it; only the rounding of the record sums changes
  * (deterministically for a given order).  CELL sorts each scan by the map-grid cell of its points

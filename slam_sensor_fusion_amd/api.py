@@ -516,6 +516,14 @@ class Icp:
         _check(self.lib.sf_icp_fused_count(self.h, C.byref(a)))
         return a.value
 
+    def fused_redone(self):
+        n = C.c_int64()
+        _check(self.lib.sf_icp_fused_redone(self.h, C.byref(n)))
+        return n.value
+
+    def test_inject_barrier_timeout(self):
+        _check(self.lib.sf_icp_test_inject_barrier_timeout(self.h))
+
     def set_nn_reuse(self, on=True):
         _check(self.lib.sf_icp_set_nn_reuse(self.h, C.c_int(int(on))))
 

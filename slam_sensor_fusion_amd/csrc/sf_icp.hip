@@ -32,6 +32,7 @@
 #include <cfloat>
 #include <cmath>
 #include <vector>
+#include <mutex>
 #include <string>
 
 namespace {
@@ -1393,7 +1394,7 @@ __device__ __forceinline__ void ref_take_step(IcpState *S, const double *rec, fl
 
 // phase 0: after the initial search (cpp:195-200); phase 1: top of loop iteration
 // (cpp:209-224); phase 2: after a lazy re-search (cpp:223-226).  One lane; rec = the record of the live pairs.
-__device__ __forceinline__ void ref_decide(IcpState *S, const double *rec, const IcpParams &prm, int phase)
+__device__ __forceinline__ void ref_decide(IcpState *S, const double *rec, const IcpParams prm, int phase)
 {
     for (int c = 0; c < NREC_P2P; ++c) S->rec[c] = rec[c];
     const double n = rec[0];
@@ -1448,8 +1449,12 @@ __global__ __launch_bounds__(RBLK) void k_ref_decide(IcpState *__restrict__ st, 
 // workgroup barrier, plain loads (MI355X: per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed
 // by another CU's stores -- workgroup scope is not enough).  Every spin is bounded (FUSED_SPIN_TICKS of the 100 MHz
 // clock): a workgroup that gives up raises SF_ICP_FLAG_BARRIER_TIMEOUT in the state and leaves, so the grid always
-// drains; the host turns the flag into an error.
-constexpr long long FUSED_SPIN_TICKS = 200000000; // 2 s
+// drains; the host then redoes that alignment through the launch list (sf_icp_fetch_results) -- the caller never sees it.
+// Residency is what the barrier rests on: the library keeps a per-device ledger of the single-launch grids in flight
+// (all contexts of the process) and admits a new one only while the sum of their shares of the device stays below one;
+// what does not fit takes the launch list.  Another PROCESS on the device is beyond the ledger: that is what the
+// bounded spin and the redo are for.
+constexpr long long FUSED_SPIN_TICKS = 50000000; // 0.5 s (a barrier normally completes in microseconds; a timed-out alignment is redone through the launch list)
 #ifdef SF_FUSED_TRACE
 __device__ unsigned long long g_fused_trace[512];
 #define FTRACE(code) do { if (bx == 0 && b == 0 && threadIdx.x == 0 && tr_n < 511) g_fused_trace[1 + tr_n++] = ((unsigned long long)wall_clock64() << 8) | (unsigned)(code); } while (0)
@@ -1562,7 +1567,7 @@ __global__ __launch_bounds__(BLK) void k_ref_fused(SfGrid g, SfWindow w, const f
         if (alive) reduce_partials<NREC_P2P, BLK>(slab, nblocks, rec);
         FTRACE(4);
     };
-    auto decide = [&](int phase) {
+    auto decide = [&, prm](int phase) {
         if (threadIdx.x == 0) ref_decide(&S, rec, prm, phase);
         __syncthreads();
         FTRACE(5);
@@ -1792,6 +1797,9 @@ struct sf_icp {
     bool last_fused = false; // the last alignment ran as the single launch
     sf::DevBuf bar;          // per scan: {arrival counter, departure counter} of the grid barrier
     int fused_limit[3] = {-1, -1, -1}; // per mode: workgroups that are certainly resident together (-1: not asked yet)
+    double fused_share = 0.0; // share of the device the single-launch grid in flight holds in the ledger (0: none)
+    int64_t fused_redone = 0; // alignments redone through the launch list after a barrier gave up
+    bool inject_timeout = false; // test hook (sf_icp_test_inject_barrier_timeout): treat the next single-launch alignment as timed out
     int64_t fused_launches = 0;
     IcpState *h_pin = nullptr; // pinned, device-visible: the single-launch forms write the final states here themselves (no copy back)
     size_t h_pin_cap = 0;
@@ -2167,11 +2175,39 @@ int fused_capacity(sf_icp *icp, int mode)
     return slot;
 }
 
+// single-launch grids in flight per device, as shares of what the device can hold resident (all contexts of this process)
+struct FusedLedger {
+    std::mutex mu;
+    double used[64] = {};
+} g_fused_ledger;
+
+void fused_release(sf_icp *icp)
+{
+    if (icp->fused_share <= 0.0) return;
+    std::lock_guard<std::mutex> lk(g_fused_ledger.mu);
+    double &u = g_fused_ledger.used[icp->ctx->device & 63];
+    u = std::max(0.0, u - icp->fused_share);
+    icp->fused_share = 0.0;
+}
+
+bool fused_reserve(sf_icp *icp, double share)
+{
+    std::lock_guard<std::mutex> lk(g_fused_ledger.mu);
+    double &u = g_fused_ledger.used[icp->ctx->device & 63];
+    if (u + share > 1.0 + 1e-9) return false;
+    u += share;
+    icp->fused_share = share;
+    return true;
+}
+
 bool fused_eligible(sf_icp *icp, int mode)
 {
     const int64_t rows = mode == SF_ICP_REF_CPP ? icp->nblocks : icp->nblocks_nn;
     // the single-launch kernels keep one point per lane (rows of 256): wide scans (qpl > 1) are not theirs
-    return icp->fused && !icp->profiling && !icp->shard && (mode == SF_ICP_REF_CPP || icp->qpl == 1) && rows * icp->batch <= (int64_t)fused_capacity(icp, mode);
+    const int64_t cap = fused_capacity(icp, mode);
+    if (!(icp->fused && !icp->profiling && !icp->shard && (mode == SF_ICP_REF_CPP || icp->qpl == 1) && cap > 0 && rows * icp->batch <= cap)) return false;
+    fused_release(icp); // the previous alignment of this object has been fetched or superseded
+    return fused_reserve(icp, (double)(rows * icp->batch) / (double)cap);
 }
 
 template <int MODE>
@@ -2231,19 +2267,23 @@ int launch_fused(sf_icp *icp, int mode)
     return SF_OK;
 }
 
-// a grid barrier of the single-launch form gave up (it never should: the grid is sized to be resident): the counters are
-// put back and the alignment is reported as failed
+// a grid barrier of the single-launch form gave up (another process holding the CUs its workgroups needed): the counters
+// are put back, this object takes the launch list from now on, and the alignment is redone that way -- the initial
+// transforms and the source are untouched, so the caller gets the result it asked for, late
+int redo_after_barrier_timeout(sf_icp *icp);
 int check_barrier_flags(sf_icp *icp)
 {
     if (!icp->last_fused) return SF_OK;
     bool bad = false;
     for (int b = 0; b < icp->batch; ++b) bad = bad || (icp->h_state[(size_t)b].flags & SF_ICP_FLAG_BARRIER_TIMEOUT);
+    bad = bad || icp->inject_timeout;
+    icp->inject_timeout = false;
     if (!bad) return SF_OK;
     hipError_t e = hipMemsetAsync(icp->bar.p, 0, icp->bar.cap, icp->ctx->stream);
     (void)e;
     for (int &v : icp->fused_limit) v = 0; // no second attempt on this object
-    sf::set_error("single-launch alignment: a grid barrier timed out (results invalid); the launch list is used from now on");
-    return SF_ERR_HIP;
+    icp->fused_redone += 1;
+    return redo_after_barrier_timeout(icp);
 }
 
 int check_ready(sf_icp *icp, int mode)
@@ -2326,6 +2366,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     if (!icp) return;
     hipError_t e = hipStreamSynchronize(icp->ctx->stream);
     (void)e;
+    fused_release(icp);
     if (icp->graph_exec) { e = hipGraphExecDestroy(icp->graph_exec); (void)e; }
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
     if (icp->inits_ev) { e = hipEventDestroy(icp->inits_ev); (void)e; }
@@ -2507,6 +2548,21 @@ extern "C" int sf_icp_fused_count(sf_icp *icp, int64_t *launches)
     return SF_OK;
 }
 
+extern "C" int sf_icp_fused_redone(sf_icp *icp, int64_t *redone)
+{
+    SF_CHECK(icp && redone, SF_ERR_INVALID, "bad arguments");
+    *redone = icp->fused_redone;
+    return SF_OK;
+}
+
+// test hook: the next single-launch alignment of this object is handled as if one of its grid barriers had given up
+extern "C" int sf_icp_test_inject_barrier_timeout(sf_icp *icp)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    icp->inject_timeout = true;
+    return SF_OK;
+}
+
 extern "C" int sf_icp_use_graph(sf_icp *icp, int on)
 {
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
@@ -2563,11 +2619,23 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     return enqueue_align(icp, mode);
 }
 
+namespace {
+int redo_after_barrier_timeout(sf_icp *icp)
+{
+    SF_TRY(sf_icp_align_batch_async(icp, icp->last_mode)); // fused_limit is zero now: the launch list
+    SF_TRY(states_to_host(icp));
+    for (int b = 0; b < icp->batch; ++b)
+        SF_CHECK(!(icp->h_state[(size_t)b].flags & SF_ICP_FLAG_BARRIER_TIMEOUT), SF_ERR_HIP, "alignment redone through the launch list still carries a barrier flag");
+    return SF_OK;
+}
+} // namespace
+
 extern "C" int sf_icp_fetch_results(sf_icp *icp, sf_icp_result *out)
 {
     SF_CHECK(icp && out, SF_ERR_INVALID, "bad arguments");
     SF_CHECK(icp->batch > 0, SF_ERR_STATE, "nothing to fetch");
     SF_TRY(states_to_host(icp));
+    fused_release(icp); // the grid has drained
     if (icp->profiling) prof_collect(icp);
     SF_TRY(check_barrier_flags(icp));
     for (int b = 0; b < icp->batch; ++b) fill_result(icp, icp->last_mode, icp->h_state[(size_t)b], &icp->inits[(size_t)b * 16], out + b);
