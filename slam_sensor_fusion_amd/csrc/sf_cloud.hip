@@ -7,7 +7,7 @@
 // instead of "build a kd-tree over the whole cloud for one radius query" (hpp:37-45).
 #include "sf_common.hpp"
 
-#include <rocprim/rocprim.hpp>
+#include "sf_sort.hpp"
 
 #include <atomic>
 #include <cstring>
@@ -500,19 +500,19 @@ extern "C" int sf_cloud_crop_radius(sf_cloud *c, const float center[3], double r
     if (rc == SF_OK && sorted && c->n > 1) {
         int64_t k = c->n;
         sf::DevBuf keys, keys2, out;
+        const uint64_t *sorted_keys = nullptr;
         rc = keys.reserve(sizeof(uint64_t) * (size_t)k);
         if (rc == SF_OK) rc = keys2.reserve(sizeof(uint64_t) * (size_t)k);
         if (rc == SF_OK) rc = out.reserve(sizeof(float) * 3 * (size_t)k);
         if (rc == SF_OK) {
             hipLaunchKernelGGL(k_pack_d2_idx, dim3(nblk(k)), dim3(256), 0, ctx->stream, d2.as<float>(), c->last_idx.as<int32_t>(), k, keys.as<uint64_t>());
-            size_t tmp = 0;
-            hipError_t e = rocprim::radix_sort_keys(nullptr, tmp, keys.as<uint64_t>(), keys2.as<uint64_t>(), (size_t)k, 0, 64, ctx->stream);
-            if (e == hipSuccess) rc = sf::ensure_scratch(ctx, tmp);
-            if (e == hipSuccess && rc == SF_OK)
-                e = rocprim::radix_sort_keys(ctx->scratch.p, tmp, keys.as<uint64_t>(), keys2.as<uint64_t>(), (size_t)k, 0, 64, ctx->stream);
-            if (e != hipSuccess) { sf::set_error("radix_sort_keys: %s", hipGetErrorString(e)); rc = SF_ERR_HIP; }
+            // (d2 bits, index) packed: d2 >= 0, so the unsigned order of the float bits is the numeric order; all 64 bits
+            uint64_t *sk = nullptr;
+            uint32_t *sv = nullptr;
+            rc = sf::radix_sort_pairs<uint64_t>(ctx, keys.as<uint64_t>(), keys2.as<uint64_t>(), nullptr, nullptr, k, 64, &sk, &sv);
+            sorted_keys = sk;
             if (rc == SF_OK) {
-                hipLaunchKernelGGL(k_gather_by_key, dim3(nblk(k)), dim3(256), 0, ctx->stream, orig.as<float>(), keys2.as<uint64_t>(), k, out.as<float>(), c->last_idx.as<int32_t>());
+                hipLaunchKernelGGL(k_gather_by_key, dim3(nblk(k)), dim3(256), 0, ctx->stream, orig.as<float>(), sorted_keys, k, out.as<float>(), c->last_idx.as<int32_t>());
                 hipError_t e2 = hipStreamSynchronize(ctx->stream);
                 if (e2 != hipSuccess) { sf::set_error("sync: %s", hipGetErrorString(e2)); rc = SF_ERR_HIP; }
                 else c->xyz.swap(out);

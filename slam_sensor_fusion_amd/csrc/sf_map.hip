@@ -10,7 +10,7 @@
 #include "sf_common.hpp"
 #include "sf_nn.hpp"
 
-#include <rocprim/rocprim.hpp>
+#include "sf_sort.hpp"
 #include <cmath>
 
 namespace {
@@ -188,26 +188,24 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
     SF_TRY(m->pts4.reserve(sizeof(float4) * np));
     SF_TRY(m->inv_perm.reserve(sizeof(uint32_t) * np));
     SF_TRY(m->cell_start.reserve(sizeof(uint32_t) * ((size_t)g.ncell + 8))); // [pad | start[0..ncell] | pad..]: sf_nn.hpp reads start[c-1..c+2] in one load
+    const void *sorted_keys = m->keys2.p; // where the sort leaves its result (either ping-pong buffer)
+    uint32_t *sorted_vals = m->vals2.as<uint32_t>();
     if (n > 0) {
         unsigned bits = 1;
         while (bits < 64 && (1ull << bits) <= (unsigned long long)g.ncell) ++bits;
-        size_t tmp = 0;
-        hipError_t e;
+        // stable: points of a cell stay in ascending point id (deterministic in-cell order => deterministic tie-breaks)
         if (wide) {
             hipLaunchKernelGGL(k_cell_keys<uint64_t>, dim3(nblk(n)), dim3(256), 0, st, xyz, n, g, m->keys.as<uint64_t>(), m->vals.as<uint32_t>());
-            e = rocprim::radix_sort_pairs(nullptr, tmp, m->keys.as<uint64_t>(), m->keys2.as<uint64_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), (size_t)n, 0, bits, st);
-            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs(size): %s", hipGetErrorString(e));
-            SF_TRY(sf::ensure_scratch(ctx, tmp));
-            e = rocprim::radix_sort_pairs(ctx->scratch.p, tmp, m->keys.as<uint64_t>(), m->keys2.as<uint64_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), (size_t)n, 0, bits, st);
+            uint64_t *sk = nullptr;
+            SF_TRY(sf::radix_sort_pairs<uint64_t>(ctx, m->keys.as<uint64_t>(), m->keys2.as<uint64_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), n, bits, &sk, &sorted_vals));
+            sorted_keys = sk;
         } else {
             hipLaunchKernelGGL(k_cell_keys<uint32_t>, dim3(nblk(n)), dim3(256), 0, st, xyz, n, g, m->keys.as<uint32_t>(), m->vals.as<uint32_t>());
-            e = rocprim::radix_sort_pairs(nullptr, tmp, m->keys.as<uint32_t>(), m->keys2.as<uint32_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), (size_t)n, 0, bits, st);
-            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs(size): %s", hipGetErrorString(e));
-            SF_TRY(sf::ensure_scratch(ctx, tmp));
-            e = rocprim::radix_sort_pairs(ctx->scratch.p, tmp, m->keys.as<uint32_t>(), m->keys2.as<uint32_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), (size_t)n, 0, bits, st);
+            uint32_t *sk = nullptr;
+            SF_TRY(sf::radix_sort_pairs<uint32_t>(ctx, m->keys.as<uint32_t>(), m->keys2.as<uint32_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), n, bits, &sk, &sorted_vals));
+            sorted_keys = sk;
         }
-        SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n)), dim3(256), 0, st, xyz, m->vals2.as<uint32_t>(), n, m->pts4.as<float4>(), m->inv_perm.as<uint32_t>());
+        hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n)), dim3(256), 0, st, xyz, sorted_vals, n, m->pts4.as<float4>(), m->inv_perm.as<uint32_t>());
     }
     uint32_t *cs = m->cell_start.as<uint32_t>() + 1;
     if (by_scan && n_valid > 0) {
@@ -215,25 +213,20 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
         // (the carry is the entry before the piece); the trailing pads come out as n_valid like the rest of the tail
         const size_t entries = (size_t)g.ncell + 8;
         SF_HIP(hipMemsetAsync(m->cell_start.p, 0, sizeof(uint32_t) * entries, st));
-        if (wide) hipLaunchKernelGGL(k_cell_tails<uint64_t>, dim3(nblk(n_valid)), dim3(256), 0, st, m->keys2.as<uint64_t>(), n_valid, cs);
-        else hipLaunchKernelGGL(k_cell_tails<uint32_t>, dim3(nblk(n_valid)), dim3(256), 0, st, m->keys2.as<uint32_t>(), n_valid, cs);
+        if (wide) hipLaunchKernelGGL(k_cell_tails<uint64_t>, dim3(nblk(n_valid)), dim3(256), 0, st, static_cast<const uint64_t *>(sorted_keys), n_valid, cs);
+        else hipLaunchKernelGGL(k_cell_tails<uint32_t>, dim3(nblk(n_valid)), dim3(256), 0, st, static_cast<const uint32_t *>(sorted_keys), n_valid, cs);
         const size_t piece = (size_t)1 << 30;
         uint32_t *t = m->cell_start.as<uint32_t>();
         for (size_t off = 0; off < entries; off += piece) {
             const size_t len = std::min(piece, entries - off);
             if (off > 0) hipLaunchKernelGGL(k_carry_max, dim3(1), dim3(1), 0, st, t + off);
-            size_t tmp = 0;
-            hipError_t e = rocprim::inclusive_scan(nullptr, tmp, t + off, t + off, len, rocprim::maximum<uint32_t>(), st);
-            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "inclusive_scan(size): %s", hipGetErrorString(e));
-            SF_TRY(sf::ensure_scratch(ctx, tmp));
-            e = rocprim::inclusive_scan(ctx->scratch.p, tmp, t + off, t + off, len, rocprim::maximum<uint32_t>(), st);
-            SF_CHECK(e == hipSuccess, SF_ERR_HIP, "inclusive_scan: %s", hipGetErrorString(e));
+            SF_TRY(sf::scan_u32<1>(ctx, t + off, t + off, (int64_t)len)); // (the carry of a later piece sits in its first entry: k_carry_max)
         }
     } else {
         hipLaunchKernelGGL(k_fill_u32, dim3(nblk((int64_t)g.ncell + 8)), dim3(256), 0, st, m->cell_start.as<uint32_t>(), (int64_t)g.ncell + 8, (uint32_t)n_valid);
         SF_HIP(hipMemsetAsync(m->cell_start.p, 0, sizeof(uint32_t), st));
         if (n_valid > 0)
-            hipLaunchKernelGGL(k_cell_bounds, dim3(nblk(n_valid)), dim3(256), 0, st, m->keys2.as<uint32_t>(), n_valid, (uint32_t)g.ncell, cs);
+            hipLaunchKernelGGL(k_cell_bounds, dim3(nblk(n_valid)), dim3(256), 0, st, static_cast<const uint32_t *>(sorted_keys), n_valid, (uint32_t)g.ncell, cs);
         else
             hipLaunchKernelGGL(k_fill_u32, dim3(nblk((int64_t)g.ncell + 2)), dim3(256), 0, st, cs, (int64_t)g.ncell + 2, 0u);
     }

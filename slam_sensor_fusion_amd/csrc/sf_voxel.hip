@@ -8,12 +8,13 @@
 // SF_VOXEL_O3D restates Open3D voxel_down_sample (float64) as called at
 // localization_python/localization_python/localization_node.py:47: index
 // floor((p - (min_bound - v/2)) / v), float64 mean per voxel.
-// Pipeline: key kernel -> stable rocPRIM radix sort of (key, point id) -> head flags ->
-// exclusive scan -> one lane per voxel sums its points sequentially in ascending point
+// Pipeline: key kernel -> stable radix sort of (key, point id) (sf_sort.hpp, hand-written) -> head flags ->
+// exclusive scan (sf_sort.hpp) -> one lane per voxel sums its points sequentially in ascending point
 // id (so the float32 / float64 sums are bit-identical to the oracle's) -> scatter.
 #include "sf_common.hpp"
 
-#include <rocprim/rocprim.hpp>
+#include "sf_sort.hpp"
+
 #include <climits>
 #include <cmath>
 
@@ -21,7 +22,7 @@ namespace {
 
 inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)sf::div_up(n > 0 ? n : 1, b); }
 
-struct PclGeom { float inv; int min_b[3]; int64_t mul[3]; };
+struct PclGeom { float inv; int min_b[3]; int64_t mul[3]; uint64_t invalid_key; /* one past the largest voxel index: non-finite points sort last */ };
 
 // K = uint32_t / ID = int32_t: pcl::VoxelGrid's int32 linear index (SF_VOXEL_PCL);
 // K = uint64_t / ID = int64_t: the same arithmetic with the index kept in 64 bits (SF_VOXEL_PCL64)
@@ -31,7 +32,7 @@ __global__ void k_pcl_keys(const float *__restrict__ xyz, int64_t n, PclGeom g, 
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    K key = ~(K)0;
+    K key = (K)g.invalid_key;
     ID id = -1;
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
         // voxel_grid.hpp: static_cast<int>(std::floor(p.x * inverse_leaf_size_[0]) - static_cast<float>(min_b_[0]))
@@ -122,12 +123,7 @@ int scan_heads(sf_ctx *ctx, const K *keys, int64_t n_valid, uint32_t *flags, uin
 {
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(k_heads<K>, dim3(nblk(n_valid)), dim3(256), 0, st, keys, n_valid, flags);
-    size_t tmp = 0;
-    hipError_t e = rocprim::exclusive_scan(nullptr, tmp, flags, pos, 0u, (size_t)n_valid, rocprim::plus<uint32_t>(), st);
-    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "exclusive_scan(size): %s", hipGetErrorString(e));
-    SF_TRY(sf::ensure_scratch(ctx, tmp));
-    e = rocprim::exclusive_scan(ctx->scratch.p, tmp, flags, pos, 0u, (size_t)n_valid, rocprim::plus<uint32_t>(), st);
-    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "exclusive_scan: %s", hipGetErrorString(e));
+    SF_TRY(sf::scan_u32<0>(ctx, flags, pos, n_valid));
     uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
     SF_HIP(hipMemcpyAsync(h, pos + (n_valid - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SF_HIP(hipMemcpyAsync(h + 1, flags + (n_valid - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -166,7 +162,8 @@ int voxel_pcl(sf_cloud *c, float leaf, int *status_flags)
     g.mul[0] = 1; g.mul[1] = div_b[0]; g.mul[2] = div_b[0] * div_b[1];
     if (WIDE) SF_CHECK((double)div_b[0] * (double)div_b[1] * (double)div_b[2] < 9.0e18, SF_ERR_OVERFLOW, "voxel index does not fit 63 bits");
 
-    sf::DevBuf keys, keys2, vals, vals2, flags, pos;
+    // temporaries live in the context (a growing map re-voxelises every few scans: no hipMalloc / hipFree per call)
+    sf::DevBuf &keys = ctx->vox_tmp[0], &keys2 = ctx->vox_tmp[1], &vals = ctx->vox_tmp[2], &vals2 = ctx->vox_tmp[3], &flags = ctx->vox_tmp[4], &pos = ctx->vox_tmp[5];
     sf::DevBuf &out = c->spare;
     SF_TRY(keys.reserve(sizeof(K) * (size_t)n));
     SF_TRY(keys2.reserve(sizeof(K) * (size_t)n));
@@ -175,23 +172,21 @@ int voxel_pcl(sf_cloud *c, float leaf, int *status_flags)
     SF_TRY(flags.reserve(sizeof(uint32_t) * (size_t)n));
     SF_TRY(pos.reserve(sizeof(uint32_t) * (size_t)n));
     SF_TRY(c->vox_point_ids.reserve(sizeof(ID) * (size_t)n));
+    g.invalid_key = (uint64_t)div_b[0] * (uint64_t)div_b[1] * (uint64_t)div_b[2];
     hipLaunchKernelGGL((k_pcl_keys<K, ID>), dim3(nblk(n)), dim3(256), 0, st, c->xyz.as<float>(), n, g, keys.as<K>(), vals.as<uint32_t>(), c->vox_point_ids.as<ID>());
-    size_t tmp = 0;
-    const unsigned end_bit = 8 * sizeof(K); // every bit: non-finite points carry the all-ones key and must sort last
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, keys.as<K>(), keys2.as<K>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), (size_t)n, 0, end_bit, st);
-    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs(size): %s", hipGetErrorString(e));
-    SF_TRY(sf::ensure_scratch(ctx, tmp));
-    e = rocprim::radix_sort_pairs(ctx->scratch.p, tmp, keys.as<K>(), keys2.as<K>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), (size_t)n, 0, end_bit, st);
-    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "radix_sort_pairs: %s", hipGetErrorString(e));
+    unsigned end_bit = 1; // the bits of the largest key in use (invalid_key itself when a point is not finite)
+    while (end_bit < 8 * sizeof(K) && (g.invalid_key >> end_bit) != 0) ++end_bit;
+    K *skeys = nullptr;
+    uint32_t *svals = nullptr;
+    SF_TRY(sf::radix_sort_pairs<K>(ctx, keys.as<K>(), keys2.as<K>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), n, end_bit, &skeys, &svals));
     int64_t n_vox = 0;
-    SF_TRY(scan_heads<K>(ctx, keys2.as<K>(), mm.n_finite, flags.as<uint32_t>(), pos.as<uint32_t>(), &n_vox));
+    SF_TRY(scan_heads<K>(ctx, skeys, mm.n_finite, flags.as<uint32_t>(), pos.as<uint32_t>(), &n_vox));
     SF_TRY(out.reserve(sizeof(float) * 3 * (size_t)n_vox));
     SF_TRY(c->vox_out_ids.reserve(sizeof(ID) * (size_t)n_vox));
-    hipLaunchKernelGGL((k_pcl_centroids<K, ID>), dim3(nblk(mm.n_finite)), dim3(256), 0, st, c->xyz.as<float>(), keys2.as<K>(), vals2.as<uint32_t>(), flags.as<uint32_t>(),
+    hipLaunchKernelGGL((k_pcl_centroids<K, ID>), dim3(nblk(mm.n_finite)), dim3(256), 0, st, c->xyz.as<float>(), skeys, svals, flags.as<uint32_t>(),
                        pos.as<uint32_t>(), mm.n_finite, out.as<float>(), c->vox_out_ids.as<ID>());
-    e = hipStreamSynchronize(st); // the temporaries above are freed on return
-    SF_CHECK(e == hipSuccess, SF_ERR_HIP, "voxel kernels: %s", hipGetErrorString(e));
-    c->xyz.swap(out);
+    SF_HIP(hipGetLastError());
+    c->xyz.swap(out); // stream-ordered: nothing here is freed
     c->n_vox_point_vals = n;
     c->n_vox_out_vals = n_vox;
     c->n_vox_out_pts = 0;
@@ -220,7 +215,7 @@ int voxel_o3d(sf_cloud *c, double voxel)
     SF_CHECK(!(voxel * (double)INT_MAX < span), SF_ERR_OVERFLOW, "voxel_size is too small.");
     SF_CHECK(span / voxel + 2 < 2097152.0, SF_ERR_OVERFLOW, "more than 2^21 voxels along one axis");
 
-    sf::DevBuf keys, keys2, vals, vals2, flags, pos; // freed on return (every path)
+    sf::DevBuf &keys = ctx->vox_tmp[0], &keys2 = ctx->vox_tmp[1], &vals = ctx->vox_tmp[2], &vals2 = ctx->vox_tmp[3], &flags = ctx->vox_tmp[4], &pos = ctx->vox_tmp[5];
     sf::DevBuf &out = c->spare;
 #define VX_TRY(e) SF_TRY(e)
     VX_TRY(keys.reserve(sizeof(uint64_t) * (size_t)n));
@@ -231,21 +226,17 @@ int voxel_o3d(sf_cloud *c, double voxel)
     VX_TRY(pos.reserve(sizeof(uint32_t) * (size_t)n));
     VX_TRY(c->vox_point_ids.reserve(sizeof(int32_t) * 3 * (size_t)n));
     hipLaunchKernelGGL(k_o3d_keys, dim3(nblk(n)), dim3(256), 0, st, c->xyz.as<float>(), n, g, keys.as<uint64_t>(), vals.as<uint32_t>(), c->vox_point_ids.as<int32_t>());
-    size_t tmp = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), (size_t)n, 0, 63, st);
-    if (e != hipSuccess) { sf::set_error("radix_sort_pairs(size): %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
-    VX_TRY(sf::ensure_scratch(ctx, tmp));
-    e = rocprim::radix_sort_pairs(ctx->scratch.p, tmp, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), (size_t)n, 0, 63, st);
-    if (e != hipSuccess) { sf::set_error("radix_sort_pairs: %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
+    uint64_t *skeys = nullptr;
+    uint32_t *svals = nullptr;
+    VX_TRY(sf::radix_sort_pairs<uint64_t>(ctx, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), n, 63, &skeys, &svals));
     int64_t n_vox = 0;
-    VX_TRY(scan_heads<uint64_t>(ctx, keys2.as<uint64_t>(), n, flags.as<uint32_t>(), pos.as<uint32_t>(), &n_vox));
+    VX_TRY(scan_heads<uint64_t>(ctx, skeys, n, flags.as<uint32_t>(), pos.as<uint32_t>(), &n_vox));
     VX_TRY(out.reserve(sizeof(float) * 3 * (size_t)n_vox));
     VX_TRY(c->vox_out_ids.reserve(sizeof(int32_t) * 3 * (size_t)n_vox));
     VX_TRY(c->vox_out_means.reserve(sizeof(double) * 3 * (size_t)n_vox));
-    hipLaunchKernelGGL(k_o3d_means, dim3(nblk(n)), dim3(256), 0, st, c->xyz.as<float>(), keys2.as<uint64_t>(), vals2.as<uint32_t>(), flags.as<uint32_t>(), pos.as<uint32_t>(), n,
+    hipLaunchKernelGGL(k_o3d_means, dim3(nblk(n)), dim3(256), 0, st, c->xyz.as<float>(), skeys, svals, flags.as<uint32_t>(), pos.as<uint32_t>(), n,
                        out.as<float>(), c->vox_out_means.as<double>(), c->vox_out_ids.as<int32_t>());
-    e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { sf::set_error("voxel kernels: %s", hipGetErrorString(e)); VX_TRY(SF_ERR_HIP); }
+    SF_HIP(hipGetLastError());
 #undef VX_TRY
     c->xyz.swap(out);
     c->vox_wide = false;

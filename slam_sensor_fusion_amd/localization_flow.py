@@ -356,8 +356,11 @@ class ImuEkfMappingFlow(EkfLocalizationFlow):
             self.on_grow(self)
         self.map_full_.append(self.pending_)
         self.map_full_.voxel_downsample(self.voxel_, self.voxel_flavour_)
-        self.index_cloud_.copy_from(self.map_full_)
-        self.index_cloud_.subsample(self.index_stride_)
+        if self.index_stride_ == 1:                           # the index is built straight from the voxel-filtered map (it copies what it needs)
+            self.index_cloud_ = self.map_full_
+        else:
+            self.index_cloud_.copy_from(self.map_full_)
+            self.index_cloud_.subsample(self.index_stride_)
         self.map_index_.build(self.index_cloud_, 0.0)
         self.map_cloud_ = self.index_cloud_
         self.icp_.set_target(self.map_index_)
