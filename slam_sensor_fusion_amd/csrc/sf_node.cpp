@@ -33,7 +33,7 @@ struct sf_node {
     std::vector<double> altitude_table; // rows of (lat, lon, alt)
     float map_T_sensor[16], odom_T_sensor_previous[16], map_T_ref[16];
     float current_compass_yaw = 0.0f;
-    bool first_time = true, have_window = false, coarse_alignment_complete = false;
+    bool first_time = true, have_window = false, window_empty = false, coarse_alignment_complete = false;
 };
 
 namespace {
@@ -131,9 +131,15 @@ int callback_body(sf_node *n, const sf_gps_fix *gps, const sf_odom *odom, const 
     sf_fusion_mat4f_inverse(n->map_T_sensor, inv);
     sf_fusion_mat4f_mul(inv, n->map_T_ref, sensor_T_ref);
     const float dx = sensor_T_ref[3], dy = sensor_T_ref[7], dz = sensor_T_ref[11];
-    if (sqrtf(dx * dx + dy * dy + dz * dz) > n->prm.ref_frame_distance || !n->have_window) {
+    // re-crop when the sensor has moved on -- or while the crop holds no point at all (ref_cropped_map_cloud_->empty(), :299:
+    // e.g. a first fix more than the crop radius away from the map), every callback, until it holds one
+    if (sqrtf(dx * dx + dy * dy + dz * dz) > n->prm.ref_frame_distance || !n->have_window || n->window_empty) {
         const float c[3] = {n->map_T_sensor[3], n->map_T_sensor[7], n->map_T_sensor[11]};
         SF_TRY(sf_map_window_sphere(n->map_index, c, (double)n->prm.cloud_crop_radius));
+        int32_t any = -1;
+        float any_d2 = 0.0f;
+        SF_TRY(sf_map_nn(n->map_index, c, 1, INFINITY, &any, &any_d2)); // the window's nearest point to its centre: none = the crop is empty
+        n->window_empty = any < 0;
         SF_TRY(sf_icp_set_target_map(n->icp, n->map_index)); // icp_->setTargetPointCloud(ref_cropped_map_cloud_), :303
         n->have_ref_cropped = false;
         std::memcpy(n->map_T_ref, n->map_T_sensor, sizeof(float) * 16);

@@ -54,6 +54,7 @@ class LocalizationFlow:
         self.odom_T_sensor_previous_ = np.eye(4, dtype=np.float32)
         self.map_T_ref_ = np.eye(4, dtype=np.float32)
         self.have_window_ = False
+        self.window_empty_ = False
         self.current_compass_yaw_ = 0.0
         self.first_time_ = True
         self.scan_cloud_ = None
@@ -138,8 +139,10 @@ class LocalizationFlow:
         # record sums (the reference's own float32 sums depend on it far more), and the sort is 50 us + two allocations per scan
         scan.crop_radius([0.0, 0.0, 0.0], self.cloud_crop_radius_, sorted=self.pcl_crop_order_)
         sensor_T_ref = api.mat4f_mul(api.mat4f_inverse(self.map_T_sensor_), self.map_T_ref_)
-        if np.linalg.norm(sensor_T_ref[:3, 3].astype(np.float32)) > self.ref_frame_distance_ or not self.have_window_:
+        # re-crop when the sensor has moved on, or while the crop holds no point at all (ref_cropped_map_cloud_->empty(), :299)
+        if np.linalg.norm(sensor_T_ref[:3, 3].astype(np.float32)) > self.ref_frame_distance_ or not self.have_window_ or self.window_empty_:
             self.map_index_.window_sphere(self.map_T_sensor_[:3, 3], self.cloud_crop_radius_)
+            self.window_empty_ = bool(self.map_index_.nn(np.asarray(self.map_T_sensor_[:3, 3], np.float32)[None])[0][0] < 0)
             self.icp_.set_target(self.map_index_)             # icp_->setTargetPointCloud(ref_cropped_map_cloud_), :303
             self.ref_cropped_map_cloud_ = None               # materialised only if the coarse phase needs it
             self.map_T_ref_ = self.map_T_sensor_.copy()
@@ -204,7 +207,9 @@ class NativeLocalizationFlow:
         self.out_ = out
         if out.status != api.SF_NODE_OK:
             return None
-        self.last = _LazyLast(out)
+        # a copy per scan: api.Node hands out ONE structure that every callback overwrites, and flow.last of an earlier
+        # scan must keep saying what that scan saw (as LocalizationFlow.last does)
+        self.last = _LazyLast(type(out).from_buffer_copy(out))
         return np.array(out.map_T_sensor, dtype=np.float32).reshape(4, 4)
 
 

@@ -341,3 +341,43 @@ def test_two_contexts_both_on_the_single_launch_path(api, ctx, orc, synth):
     r = a.align("ref_cpp")
     assert np.array_equal(r["T64"], want[0]["T64"]) and a.fused_count() == 202
     ctx2.synchronize()
+
+
+def test_start_outside_the_map_recrops_until_the_crop_holds_points(api, ctx, orc, synth):
+    """ADVICE r2 (sf_node.cpp:134): the reference re-crops while ref_cropped_map_cloud_ is EMPTY (localization_node.cpp:299),
+    e.g. after a first fix more than the 10 m crop radius away from every map point -- every callback, not only after 3 m of
+    travel.  Native node and Python mirror agree bit for bit on the way in; flow.last of an earlier scan keeps its values."""
+    from slam_sensor_fusion_amd.localization_flow import LocalizationFlow, NativeLocalizationFlow
+    raw = synth.make_map(400_000, seed=31)                                  # x, y in [-10, 10]
+    ds = orc.voxel_pcl(raw, 0.1)[0]
+    lla0 = np.array([[-22.9068, -43.1729, 12.0]])
+    mtg = orc.map_T_global(lla0, np.zeros(1, np.float32))
+    flows = [LocalizationFlow(ctx, ds, mtg, altitude_table=lla0), NativeLocalizationFlow(ctx, ds, mtg, altitude_table=lla0)]
+    for f in flows:
+        f.coarse_alignment_complete_ = True
+    gps_cov, odom_cov = np.diag([0.25, 0.25, 0.25]).ravel(), np.diag([1e-4] * 6).ravel()
+    rng = np.random.default_rng(9)
+    recropped, kept = [], None
+    for k in range(8):
+        truth = synth.make_T((-21.5 + 1.0 * k, 0.0, 0.0), (0, 0, 0))       # starts 11.5 m west of the map's edge, 1 m per scan
+        scan = make_sensor_scan(synth, ds, synth.make_T((-8.0, 0.0, 0.0), (0, 0, 0)), 6000, 300 + k)   # (what it sees does not matter out there)
+        gps, odom = messages_for(truth, k, rng, gps_cov, odom_cov)
+        outs = []
+        for f in flows:
+            f.compassCallback(90.0)
+            outs.append(f.localizationCallback(scan, gps, odom))
+        if k == 0:
+            for f in flows:
+                f.map_T_sensor_ = truth.astype(np.float32)
+                f.map_T_ref_ = truth.astype(np.float32)
+            continue
+        assert np.array_equal(outs[0], outs[1]), k
+        recropped.append(int(flows[1].out_.recropped))
+        for f in flows:                                                  # hold the pose on the drive (nothing to register against out there)
+            f.map_T_sensor_ = truth.astype(np.float32)
+        if k == 1:
+            kept = (flows[1].last, np.array(flows[1].last["prior"]), np.array(flows[0].last["prior"]))
+    # crop centre at x = -20.5, -19.5: empty (map starts at -10, radius 10) -> re-cropped on every callback although < 3 m were
+    # travelled; from -18.5 on it holds points and the 3 m rule takes over
+    assert recropped[:3] == [1, 1, 1] and sum(recropped[3:]) <= 2, recropped
+    assert np.array_equal(kept[0]["prior"], kept[1]) and np.array_equal(kept[1], kept[2])   # flow.last of scan 1, read again six scans later
