@@ -96,10 +96,12 @@ namespace {
 constexpr int P2P_MAX_RANKS = 16;
 constexpr uint32_t P2P_MAGIC = 0x32504653u; // "SFP2"
 constexpr size_t P2P_LINE = 128;
-constexpr size_t P2P_FLAGS_OFF = 0;                                  // uint64 flag[r] at r * 128
-constexpr size_t P2P_ABORT_OFF = P2P_LINE * P2P_MAX_RANKS;           // uint32
-constexpr size_t P2P_SLOTS_OFF = P2P_ABORT_OFF + 2 * P2P_LINE;       // double slot[2][nranks][max_count]
 constexpr int P2P_BLK = 1024;
+constexpr int P2P_CHUNK = 2048;      // doubles one workgroup carries: a batch's records are split over count / 2048 workgroups,
+constexpr int P2P_MAX_CHUNKS = 64;   // each with flags of its own (a 512-scan batch at 8 GPUs is 16 384 doubles = 8 chunks)
+constexpr size_t P2P_FLAGS_OFF = 0;                                                       // uint64 flag[chunk][r] at (chunk * 16 + r) * 128
+constexpr size_t P2P_ABORT_OFF = P2P_LINE * P2P_MAX_RANKS * P2P_MAX_CHUNKS;               // uint32
+constexpr size_t P2P_SLOTS_OFF = P2P_ABORT_OFF + 2 * P2P_LINE;                            // double slot[2][nranks][max_count]
 
 struct P2pHandle { // SF_COMM_P2P_HANDLE_BYTES: what the launcher hands round
     uint32_t magic;
@@ -115,25 +117,30 @@ static_assert(sizeof(P2pHandle) == SF_COMM_P2P_HANDLE_BYTES, "handle blob size")
 
 struct P2pPeers { unsigned char *region[P2P_MAX_RANKS]; int nranks, rank; };
 
-__device__ __forceinline__ unsigned long long *p2p_flag(unsigned char *region, int r) { return reinterpret_cast<unsigned long long *>(region + P2P_FLAGS_OFF + (size_t)r * P2P_LINE); }
+__device__ __forceinline__ unsigned long long *p2p_flag(unsigned char *region, int chunk, int r)
+{
+    return reinterpret_cast<unsigned long long *>(region + P2P_FLAGS_OFF + ((size_t)chunk * P2P_MAX_RANKS + (size_t)r) * P2P_LINE);
+}
 __device__ __forceinline__ uint32_t *p2p_abort(unsigned char *region) { return reinterpret_cast<uint32_t *>(region + P2P_ABORT_OFF); }
 __device__ __forceinline__ double *p2p_slot(unsigned char *region, int parity, int r, int nranks, int64_t max_count)
 {
     return reinterpret_cast<double *>(region + P2P_SLOTS_OFF) + ((size_t)parity * (size_t)nranks + (size_t)r) * (size_t)max_count;
 }
 
-// status word (pinned host memory): 0 ok, 1 timed out waiting for a peer, 2 aborted by a peer / the host
+// status word (pinned host memory): 0 ok, 1 timed out waiting for a peer, 2 aborted by a peer / the host.
+// grid.x = chunks of P2P_CHUNK doubles; a workgroup carries its chunk through publish / signal / wait / sum on its own flags
 __global__ __launch_bounds__(P2P_BLK) void k_p2p_allreduce(P2pPeers pr, double *__restrict__ buf, int count, int64_t max_count, unsigned long long seq, long long spin_ticks,
                                                           uint32_t *__restrict__ status)
 {
     __shared__ int verdict; // 0 ok, 1 timeout, 2 abort
-    const int tid = (int)threadIdx.x, R = pr.nranks, me = pr.rank, par = (int)(seq & 1ull);
+    const int tid = (int)threadIdx.x, R = pr.nranks, me = pr.rank, par = (int)(seq & 1ull), chunk = (int)blockIdx.x;
+    const int i0 = chunk * P2P_CHUNK, i1 = min(i0 + P2P_CHUNK, count);
     unsigned char *mine = pr.region[me];
     if (tid == 0) verdict = __hip_atomic_load(p2p_abort(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 2 : 0;
     __syncthreads();
     if (verdict == 0) {
         // publish
-        for (int i = tid; i < count; i += P2P_BLK) {
+        for (int i = i0 + tid; i < i1; i += P2P_BLK) {
             const double v = buf[i];
             for (int r = 0; r < R; ++r) __hip_atomic_store(p2p_slot(pr.region[r], par, me, R, max_count) + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -146,10 +153,10 @@ __global__ __launch_bounds__(P2P_BLK) void k_p2p_allreduce(P2pPeers pr, double *
         __syncthreads();
         // signal, then wait for every rank's signal (lane r: rank r)
         if (tid < R) {
-            __hip_atomic_store(p2p_flag(pr.region[tid], me), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(p2p_flag(pr.region[tid], chunk, me), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             const long long t0 = wall_clock64();
             int v = 0;
-            while (__hip_atomic_load(p2p_flag(mine, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            while (__hip_atomic_load(p2p_flag(mine, chunk, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
                 __builtin_amdgcn_s_sleep(2);
                 if (__hip_atomic_load(p2p_abort(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { v = 2; break; }
                 if (wall_clock64() - t0 > spin_ticks) { v = 1; break; }
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(P2P_BLK) void k_p2p_allreduce(P2pPeers pr, double *
         return;
     }
     // sum in rank order
-    for (int i = tid; i < count; i += P2P_BLK) {
+    for (int i = i0 + tid; i < i1; i += P2P_BLK) {
         double s = 0.0;
         for (int r = 0; r < R; ++r) s += __hip_atomic_load(p2p_slot(mine, par, r, R, max_count) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         buf[i] = s;
@@ -265,8 +272,8 @@ extern "C" int sf_comm_create(sf_ctx *ctx, int nranks, int rank, const void *id1
 // P2P, step 1: this rank's region.  max_count = the largest all-reduce (doubles) the communicator will carry.
 extern "C" int sf_comm_p2p_create(sf_ctx *ctx, int nranks, int rank, int64_t max_count, sf_comm **out)
 {
-    SF_CHECK(ctx && out && nranks >= 1 && nranks <= P2P_MAX_RANKS && rank >= 0 && rank < nranks && max_count >= 1 && max_count <= (1ll << 24), SF_ERR_INVALID,
-             "bad arguments (1..%d ranks, 1..2^24 doubles)", P2P_MAX_RANKS);
+    SF_CHECK(ctx && out && nranks >= 1 && nranks <= P2P_MAX_RANKS && rank >= 0 && rank < nranks && max_count >= 1 && max_count <= (int64_t)P2P_CHUNK * P2P_MAX_CHUNKS, SF_ERR_INVALID,
+             "bad arguments (1..%d ranks, 1..%d doubles)", P2P_MAX_RANKS, P2P_CHUNK * P2P_MAX_CHUNKS);
     SF_HIP(hipSetDevice(ctx->device));
     sf_comm *c = new (std::nothrow) sf_comm();
     SF_CHECK(c, SF_ERR_NOMEM, "out of host memory");
@@ -485,7 +492,7 @@ int comm_allreduce_f64(sf_comm *c, void *d_buf, int64_t count)
         SF_TRY(p2p_status_to_rc(c)); // poisoned: do not enqueue more
         c->seq += 1;
         c->n_collectives += 1;
-        hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(P2P_BLK), 0, c->ctx->stream, c->peers, static_cast<double *>(d_buf), (int)count, c->max_count, c->seq,
+        hipLaunchKernelGGL(k_p2p_allreduce, dim3((unsigned)sf::div_up(count, P2P_CHUNK)), dim3(P2P_BLK), 0, c->ctx->stream, c->peers, static_cast<double *>(d_buf), (int)count, c->max_count, c->seq,
                            (long long)(c->timeout_s * 1e8), c->status); // wall_clock64 ticks at 100 MHz
         SF_HIP(hipGetLastError());
         return SF_OK;
