@@ -758,6 +758,15 @@ def main():
         if valu is not None:
             # what binds a searching launch: vector-instruction issue (profiles/: SQ_INSTS_VALU per wave, SQ_ACTIVE_INST_VALU utilisation)
             roof["valu_issue"] = valu
+        # the searching phase under its own name: counters of the same command with `--no-nn-reuse` (every query searches in every
+        # launch), taken on this build of the kernel; and the verifying phase from this run's own launch times and its compulsory stream
+        sj, _why = load_traffic("r03_search_traffic.json") if not args.no_nn_reuse else (None, None)
+        if sj is not None and sj.get("avg_launch_ns_kernel_trace"):
+            roof["searching_frac"] = {"frac": sj["frac_of_hbm_peak_kernel_trace"], "traffic_bytes_per_launch": sj["traffic_bytes_per_launch"],
+                                      "avg_launch_us": sj["avg_launch_ns_kernel_trace"] * 1e-3, "valu_busy_frac": (sj.get("valu") or {}).get("valu_busy_frac"),
+                                      "source": "profiles/r03_search_traffic.json: PMC traffic / rocprofv3 kernel-trace duration of launches in which every query searches"}
+        if sel_v.any():
+            roof["verifying_frac"] = float(comp[sel_v].mean() / (prof["ms"][sel_v].mean() * 1e-3) / 1e9 / HBM_PEAK_GBS)
 
     scans_total = B * args.steps
     value = scans_total / elapsed

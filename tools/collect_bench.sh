@@ -2,7 +2,7 @@
 # The bench lines and stream-demo lines kept under profiles/ (one gpurun call): writes gpurun_out/profiles_<P>/<P>_bench_*.json,
 # <P>_bench_sweep.jsonl and <P>_stream_demo.jsonl.   tools/collect_bench.sh r02
 set -e
-P=${1:-r02}
+P=${1:-r03}
 cd "$GRAFT_REPO_ROOT"
 OUT="$GRAFT_REPO_ROOT/gpurun_out/profiles_$P"
 mkdir -p "$OUT"

@@ -41,8 +41,17 @@ try:
                     "vector instructions, averaged over the launches of an alignment -- the roofline that binds a searching launch"}
 except (OSError, KeyError):
     pass
+avg_ns = None
+try:
+    tr = json.load(open(prefix + "_final_kernel_trace_by_grid.json"))
+    tk = max((k for k in tr if k.startswith(kname)), key=lambda k: tr[k]["launches"] * tr[k]["avg_ns"])
+    avg_ns = tr[tk]["avg_ns"]
+except (OSError, KeyError, ValueError):
+    pass
 out = {
     "kernel": key.split(" grid=")[0],
+    "avg_launch_ns_kernel_trace": avg_ns,
+    "frac_of_hbm_peak_kernel_trace": ((read_b + write_b) / (avg_ns * 1e-9) / 8e12) if avg_ns else None,
     "config": {"scan_points": 200000, "map_points": 10000000, "batch": batch, "iters": iters, "mode": mode, "nn_reuse": reuse},
     "source_hash": kernel_source_hash(),
     "queries_per_launch": q,

@@ -7,7 +7,7 @@
 # Timing pass: --kernel-trace --stats.  Counter passes: --pmc only, one group per run (gpurun refuses --pmc together with
 # tracing flags).  Command profiled: bench.py, 3 steps, no graph replay (kernels visible one by one), no extra legs.
 set -e
-P=${1:-r02}
+P=${1:-r03}
 shift || true
 EXTRA="$*"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
