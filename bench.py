@@ -765,7 +765,7 @@ def main():
             roof["searching_frac"] = {"frac": sj["frac_of_hbm_peak_kernel_trace"], "traffic_bytes_per_launch": sj["traffic_bytes_per_launch"],
                                       "avg_launch_us": sj["avg_launch_ns_kernel_trace"] * 1e-3, "valu_busy_frac": (sj.get("valu") or {}).get("valu_busy_frac"),
                                       "source": "profiles/r03_search_traffic.json: PMC traffic / rocprofv3 kernel-trace duration of launches in which every query searches"}
-        if sel_v.any():
+        if sel_v.any() and args.mode == "p2plane":   # (the other modes converge early: their later launches return at once)
             roof["verifying_frac"] = float(comp[sel_v].mean() / (prof["ms"][sel_v].mean() * 1e-3) / 1e9 / HBM_PEAK_GBS)
 
     scans_total = B * args.steps
