@@ -130,6 +130,13 @@ void sf_free(void *p);
 #define SF_VOXEL_PCL64 2
 #define SF_FLAG_VOXEL_OVERFLOW 1
 int sf_cloud_voxel_downsample(sf_cloud *c, double leaf, int flavour, int *status_flags);
+/* Incremental map growth: exactly sf_cloud_append(map, pending) + sf_cloud_voxel_downsample(map, leaf, SF_VOXEL_PCL, ...)
+ * (`*map_cloud += *cloud` + the voxel filter, global_map_frames_manager.cpp:131,142-146) -- bit for bit -- computed as a MERGE
+ * when `map` is itself voxel-filtered at that leaf: only the pending points are sorted, their voxels found among the map's by
+ * binary search, touched centroids re-summed in point order, one copy pass opens the gaps for the new voxels.  Falls back to
+ * the two calls whenever the preconditions do not hold (map keys not strictly ascending under the union's geometry, index
+ * overflow, an empty side); *merged (may be NULL) says which way it went.  Both clouds on the same context. */
+int sf_cloud_voxel_merge(sf_cloud *map, sf_cloud *pending, double leaf, int *status_flags, int *merged);
 /* introspection for parity tests: per-input-point voxel ids of the LAST downsample
  * (PCL: int32 linear index, -1 for non-finite; O3D: int32 i,j,k triplets) and the ids /
  * float64 means of the output voxels (O3D flavour keeps float64 means). */

@@ -283,6 +283,12 @@ class Cloud:
         _check(self.lib.sf_cloud_voxel_downsample(self.h, C.c_double(leaf), C.c_int(fl), C.byref(flags)))
         return flags.value
 
+    def voxel_merge(self, pending, leaf=0.1):
+        """append(pending) + voxel_downsample(leaf, "pcl") as a merge when this cloud is already voxel-filtered -> (status flags, merged?)"""
+        st, mg = C.c_int(), C.c_int()
+        _check(self.lib.sf_cloud_voxel_merge(self.h, pending.h, C.c_double(leaf), C.byref(st), C.byref(mg)))
+        return st.value, bool(mg.value)
+
     def _i32(self, fn):
         n = C.c_int64()
         fn(self.h, None, C.c_int64(0), C.byref(n))

@@ -99,6 +99,7 @@ struct sf_ctx {
     sf::DevBuf scratch;   // rocPRIM temporary storage
     sf::DevBuf scratch2;  // block counts / small reductions
     sf::DevBuf sort_hist, scan_tiles; // sf_sort.hpp: digit histograms of the radix sort, tile sums of the scans
+    sf::DevBuf merge_tmp;  // sf_cloud_voxel_merge: per-voxel tables of the pending points
     sf::DevBuf vox_tmp[6]; // voxel grids: keys, keys', point ids, point ids', head flags, positions -- kept between calls (a growing map re-voxelises every few scans)
     void *h_pinned = nullptr; // small pinned staging (4 KiB)
     // pageable -> device uploads go through two pinned buffers in turn (sf::upload_staged): the runtime's own staging of

@@ -15,6 +15,7 @@
 
 #include "sf_sort.hpp"
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 
@@ -260,6 +261,194 @@ int download_i32(sf_cloud *c, const sf::DevBuf &buf, int64_t have, int32_t *dst,
 }
 
 } // namespace
+
+// ------------------------------------------------------------------ incremental map growth: the voxel grid as a merge
+// `*map_cloud += *cloud` followed by the voxel filter (global_map_frames_manager.cpp:131,142-146) when map_cloud already
+// IS a voxel-filtered cloud (config 4: the map grows by a few registered scans at a time).  The filtered map is sorted by
+// voxel index and holds one point per voxel, so re-filtering the concatenation needs no sort of the map: key the old points
+// (they re-enter the filter as points: a centroid is keyed by where it lies, exactly as the full filter would), check that
+// the keys are strictly ascending (a centroid that rounding has pushed across a voxel face breaks that: rare -> full path),
+// sort only the pending points, find each of their voxels among the old keys by binary search, sum old point first and
+// then the pending ones in ascending id (the oracle's float32 order), and copy the map once, opening the gaps for the
+// new voxels.  The result is bit-identical to the full path (tests/test_gpu_map_growth.py, test_gpu_config4_stream.py).
+namespace {
+
+__global__ void k_check_ascending(const uint32_t *__restrict__ keys, int64_t n, uint32_t *__restrict__ bad)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > 0 && j < n && keys[j] <= keys[j - 1]) *bad = 1u;
+}
+
+// one lane per voxel of the pending points: where it goes in the old map and its centroid
+__global__ void k_merge_groups(const float *__restrict__ old_xyz, const uint32_t *__restrict__ old_keys, int64_t n_old, const float *__restrict__ new_xyz,
+                               const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos,
+                               int64_t m_valid, uint32_t *__restrict__ g_rank, uint32_t *__restrict__ g_fresh, float *__restrict__ g_centroid)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m_valid || !flags[j]) return;
+    const uint32_t key = keys[j];
+    int64_t lo = 0, hi = n_old; // first old key >= key
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (old_keys[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    const bool found = lo < n_old && old_keys[lo] == key;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    int cnt = 0;
+    if (found) { // the old point has the smallest id of its voxel: first in the sum
+        sx = __fadd_rn(sx, old_xyz[3 * lo]); sy = __fadd_rn(sy, old_xyz[3 * lo + 1]); sz = __fadd_rn(sz, old_xyz[3 * lo + 2]);
+        cnt = 1;
+    }
+    for (int64_t k = j; k < m_valid && keys[k] == key; ++k) {
+        const size_t p = vals[k];
+        sx = __fadd_rn(sx, new_xyz[3 * p]); sy = __fadd_rn(sy, new_xyz[3 * p + 1]); sz = __fadd_rn(sz, new_xyz[3 * p + 2]);
+        ++cnt;
+    }
+    const float c = (float)cnt;
+    const size_t g = pos[j];
+    g_rank[g] = (uint32_t)lo;
+    g_fresh[g] = found ? 0u : 1u;
+    g_centroid[3 * g] = __fdiv_rn(sx, c); g_centroid[3 * g + 1] = __fdiv_rn(sy, c); g_centroid[3 * g + 2] = __fdiv_rn(sz, c);
+}
+
+// the ranks of the fresh voxels, compacted (ascending, since the groups are)
+__global__ void k_merge_fresh_ranks(const uint32_t *__restrict__ g_rank, const uint32_t *__restrict__ g_fresh, const uint32_t *__restrict__ fresh_pos, int64_t n_groups,
+                                    uint32_t *__restrict__ fresh_rank)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_groups && g_fresh[g]) fresh_rank[fresh_pos[g]] = g_rank[g];
+}
+
+// old point j moves up by the number of fresh voxels that sort before it (fresh_rank <= j)
+__global__ __launch_bounds__(256) void k_merge_copy(const float *__restrict__ old_xyz, int64_t n_old, const uint32_t *__restrict__ fresh_rank, int64_t n_fresh,
+                                                     float *__restrict__ out)
+{
+    __shared__ int64_t lo_s, hi_s;
+    const int64_t j0 = (int64_t)blockIdx.x * blockDim.x, j = j0 + threadIdx.x;
+    if (threadIdx.x < 2) { // upper_bound(fresh_rank, j0 - 1 .. j0 + 255): the block's range of candidates
+        const int64_t v = threadIdx.x == 0 ? j0 - 1 : j0 + (int64_t)blockDim.x - 1;
+        int64_t lo = 0, hi = n_fresh;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)fresh_rank[mid] <= v) lo = mid + 1;
+            else hi = mid;
+        }
+        if (threadIdx.x == 0) lo_s = lo;
+        else hi_s = lo;
+    }
+    __syncthreads();
+    if (j >= n_old) return;
+    int64_t lo = lo_s, hi = hi_s;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)fresh_rank[mid] <= j) lo = mid + 1;
+        else hi = mid;
+    }
+    const size_t d = (size_t)(j + lo);
+    out[3 * d] = old_xyz[3 * j]; out[3 * d + 1] = old_xyz[3 * j + 1]; out[3 * d + 2] = old_xyz[3 * j + 2];
+}
+
+// the centroids of the touched and the fresh voxels into their places
+__global__ void k_merge_place(const uint32_t *__restrict__ g_rank, const uint32_t *__restrict__ g_fresh, const uint32_t *__restrict__ fresh_pos, const float *__restrict__ g_centroid,
+                              int64_t n_groups, float *__restrict__ out)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    // fresh_pos[g] = fresh voxels before group g: an old point of rank r has exactly that many fresh voxels sorting before it
+    const size_t d = (size_t)g_rank[g] + (size_t)fresh_pos[g];
+    out[3 * d] = g_centroid[3 * g]; out[3 * d + 1] = g_centroid[3 * g + 1]; out[3 * d + 2] = g_centroid[3 * g + 2];
+}
+
+} // namespace
+
+extern "C" int sf_cloud_voxel_merge(sf_cloud *map, sf_cloud *pending, double leaf_d, int *status_flags, int *merged)
+{
+    SF_CHECK(map && pending && map != pending && leaf_d > 0, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(map->ctx == pending->ctx, SF_ERR_INVALID, "both clouds must live on the same context");
+    if (status_flags) *status_flags = 0;
+    if (merged) *merged = 0;
+    sf_ctx *ctx = map->ctx;
+    SF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t n = map->n, m = pending->n;
+    const float leaf = (float)leaf_d, inv = 1.0f / leaf;
+    auto full_path = [&]() -> int {
+        SF_TRY(sf_cloud_append(map, pending));
+        return sf_cloud_voxel_downsample(map, leaf_d, SF_VOXEL_PCL, status_flags);
+    };
+    if (n == 0 || m == 0 || n + m >= (int64_t)0x7fffffff) return full_path();
+    // geometry of the union, as pcl::VoxelGrid computes it over the concatenated cloud
+    SF_TRY(ctx->scratch2.reserve(sizeof(sf::MinMaxDev) * 1100 + 64));
+    sf::MinMaxHost a, b;
+    SF_TRY(sf::cloud_minmax(ctx, map->xyz.as<float>(), n, &a));
+    SF_TRY(sf::cloud_minmax(ctx, pending->xyz.as<float>(), m, &b));
+    if (a.n_finite != n || b.n_finite == 0) return full_path();
+    float mn[3], mx[3];
+    for (int d = 0; d < 3; ++d) { mn[d] = std::min(a.mn[d], b.mn[d]); mx[d] = std::max(a.mx[d], b.mx[d]); }
+    const int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1, dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > (int64_t)INT32_MAX) return full_path(); // (PCL's overflow behaviour lives there)
+    PclGeom g;
+    g.inv = inv;
+    int64_t div_b[3];
+    for (int d = 0; d < 3; ++d) {
+        g.min_b[d] = (int)std::floor(mn[d] * inv);
+        div_b[d] = (int64_t)(int)std::floor(mx[d] * inv) - (int64_t)g.min_b[d] + 1;
+    }
+    g.mul[0] = 1; g.mul[1] = div_b[0]; g.mul[2] = div_b[0] * div_b[1];
+    g.invalid_key = (uint64_t)div_b[0] * (uint64_t)div_b[1] * (uint64_t)div_b[2];
+    unsigned end_bit = 1;
+    while (end_bit < 32 && (g.invalid_key >> end_bit) != 0) ++end_bit;
+
+    sf::DevBuf &old_keys = ctx->vox_tmp[0], &keys = ctx->vox_tmp[1], &vals = ctx->vox_tmp[2], &vals2 = ctx->vox_tmp[3], &flags = ctx->vox_tmp[4], &pos = ctx->vox_tmp[5];
+    sf::DevBuf &mt = ctx->merge_tmp;
+    SF_TRY(old_keys.reserve(sizeof(uint32_t) * (size_t)(n + 2 * m)));
+    SF_TRY(keys.reserve(sizeof(uint32_t) * (size_t)(n + 2 * m)));
+    SF_TRY(vals.reserve(sizeof(uint32_t) * (size_t)(n + 2 * m)));
+    SF_TRY(vals2.reserve(sizeof(uint32_t) * (size_t)(n + 2 * m)));
+    SF_TRY(flags.reserve(sizeof(uint32_t) * (size_t)(n + 2 * m)));
+    SF_TRY(pos.reserve(sizeof(uint32_t) * (size_t)(n + 2 * m)));
+    // per group: rank, fresh flag, fresh prefix, fresh ranks, centroid; + the "keys not ascending" flag
+    SF_TRY(mt.reserve(sizeof(uint32_t) * 4 * (size_t)m + sizeof(float) * 3 * (size_t)m + 64));
+    uint32_t *g_rank = mt.as<uint32_t>(), *g_fresh = g_rank + m, *fresh_pos = g_fresh + m, *fresh_rank = fresh_pos + m;
+    float *g_centroid = reinterpret_cast<float *>(fresh_rank + m);
+    uint32_t *bad = reinterpret_cast<uint32_t *>(g_centroid + 3 * m);
+    SF_TRY(map->vox_point_ids.reserve(sizeof(int32_t) * (size_t)(n + m))); // (the key kernel writes per-point ids: scratch here)
+    SF_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), st));
+    // old points: keys under the union's geometry, must be strictly ascending
+    hipLaunchKernelGGL((k_pcl_keys<uint32_t, int32_t>), dim3(nblk(n)), dim3(256), 0, st, map->xyz.as<float>(), n, g, old_keys.as<uint32_t>(), vals2.as<uint32_t>(), map->vox_point_ids.as<int32_t>());
+    hipLaunchKernelGGL(k_check_ascending, dim3(nblk(n)), dim3(256), 0, st, old_keys.as<uint32_t>(), n, bad);
+    // pending points: keys, stable sort, voxel heads
+    uint32_t *nk = keys.as<uint32_t>(), *nk2 = nk + m, *nv = vals.as<uint32_t>(), *nv2 = nv + m;
+    hipLaunchKernelGGL((k_pcl_keys<uint32_t, int32_t>), dim3(nblk(m)), dim3(256), 0, st, pending->xyz.as<float>(), m, g, nk, nv, map->vox_point_ids.as<int32_t>() + n);
+    uint32_t *sk = nullptr, *sv = nullptr;
+    SF_TRY(sf::radix_sort_pairs<uint32_t>(ctx, nk, nk2, nv, nv2, m, end_bit, &sk, &sv));
+    int64_t n_groups = 0;
+    SF_TRY(scan_heads<uint32_t>(ctx, sk, b.n_finite, flags.as<uint32_t>(), pos.as<uint32_t>(), &n_groups)); // (synchronises: the ascending check has run by now)
+    uint32_t h_bad = 0;
+    SF_HIP(hipMemcpy(&h_bad, bad, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (h_bad) return full_path();
+    hipLaunchKernelGGL(k_merge_groups, dim3(nblk(b.n_finite)), dim3(256), 0, st, map->xyz.as<float>(), old_keys.as<uint32_t>(), n, pending->xyz.as<float>(), sk, sv, flags.as<uint32_t>(),
+                       pos.as<uint32_t>(), b.n_finite, g_rank, g_fresh, g_centroid);
+    SF_TRY(sf::scan_u32<0>(ctx, g_fresh, fresh_pos, n_groups));
+    uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
+    SF_HIP(hipMemcpyAsync(h, fresh_pos + (n_groups - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SF_HIP(hipMemcpyAsync(h + 1, g_fresh + (n_groups - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SF_HIP(hipStreamSynchronize(st));
+    const int64_t n_fresh = (int64_t)h[0] + (int64_t)h[1], n_out = n + n_fresh;
+    sf::DevBuf &out = map->spare;
+    SF_TRY(out.reserve(sizeof(float) * 3 * (size_t)n_out));
+    hipLaunchKernelGGL(k_merge_fresh_ranks, dim3(nblk(n_groups)), dim3(256), 0, st, g_rank, g_fresh, fresh_pos, n_groups, fresh_rank);
+    hipLaunchKernelGGL(k_merge_copy, dim3(nblk(n)), dim3(256), 0, st, map->xyz.as<float>(), n, fresh_rank, n_fresh, out.as<float>());
+    hipLaunchKernelGGL(k_merge_place, dim3(nblk(n_groups)), dim3(256), 0, st, g_rank, g_fresh, fresh_pos, g_centroid, n_groups, out.as<float>());
+    SF_HIP(hipGetLastError());
+    map->xyz.swap(out);
+    map->n = n_out;
+    map->n_last_idx = -1;
+    map->n_vox_point_vals = map->n_vox_out_vals = map->n_vox_out_pts = 0; // (per-point / per-voxel ids are those of a full pass only)
+    if (merged) *merged = 1;
+    return SF_OK;
+}
 
 extern "C" int sf_cloud_voxel_downsample(sf_cloud *c, double leaf, int flavour, int *status_flags)
 {

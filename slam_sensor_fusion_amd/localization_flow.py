@@ -319,6 +319,7 @@ class ImuEkfMappingFlow(EkfLocalizationFlow):
         self.registered_ = api.Cloud(ctx)
         self.scans_since_growth_ = 0
         self.growths_ = 0
+        self.merges_ = 0                                      # growth steps that took the merge path of sf_cloud_voxel_merge
         self.on_grow = None                                   # test hook: on_grow(flow) just before a growth step
 
     def pose_prior(self, gps, odom, odom_T_sensor_current):
@@ -359,8 +360,12 @@ class ImuEkfMappingFlow(EkfLocalizationFlow):
     def grow_map(self):
         if self.on_grow is not None:
             self.on_grow(self)
-        self.map_full_.append(self.pending_)
-        self.map_full_.voxel_downsample(self.voxel_, self.voxel_flavour_)
+        if self.voxel_flavour_ == "pcl":                      # the voxel filter of the concatenation as a merge into the filtered map (bit-identical)
+            _, merged = self.map_full_.voxel_merge(self.pending_, self.voxel_)
+            self.merges_ += int(merged)
+        else:
+            self.map_full_.append(self.pending_)
+            self.map_full_.voxel_downsample(self.voxel_, self.voxel_flavour_)
         if self.index_stride_ == 1:                           # the index is built straight from the voxel-filtered map (it copies what it needs)
             self.index_cloud_ = self.map_full_
         else:

@@ -75,3 +75,37 @@ def test_map_grows_by_registered_scans(api, ctx, orc, synth):
     assert np.array_equal(acc.download(), np.concatenate([west[:10]] + [west[10 * k:10 * (k + 1) * (k + 1)] for k in range(1, 6)]))
     with pytest.raises(api.SlamFusionError):
         acc.append(acc)
+
+
+def test_voxel_merge_equals_append_plus_filter(api, ctx, orc, synth):
+    """sf_cloud_voxel_merge == `*map_cloud += *cloud` + VoxelGrid (global_map_frames_manager.cpp:131,142-146), bit for bit,
+    through several growth steps: pending points that hit existing voxels (centroids re-summed: old point first), that open
+    new voxels inside, before and after the map's extent (the bounding box -- hence every linear index -- changes), duplicates
+    and non-finite points; and the fall-back when the map is not a filtered cloud."""
+    rng = np.random.default_rng(5)
+    base = synth.make_map(300_000)                                   # 17 m x 17 m x 10 m
+    host = orc.voxel_pcl(base[base[:, 0] < 0.0], 0.1)[0]
+    dev = api.Cloud(ctx, host.copy())
+    assert dev.voxel_downsample(0.1, "pcl") == 0                      # (already filtered: stays itself up to merges)
+    host = orc.voxel_pcl(host, 0.1)[0]
+    assert np.array_equal(dev.download(), host)
+    steps = [base[(base[:, 0] >= -1.0) & (base[:, 0] < 2.0)][:40_000],                      # overlaps the edge: touched and new voxels
+             (base[:30_000] * [1.0, 1.0, 1.0] + [0.0, 0.0, 0.004]).astype(np.float32),      # nearly the same points again: mostly touched voxels
+             (rng.uniform(-1, 1, (5_000, 3)) * [12.0, 12.0, 8.0]).astype(np.float32),      # beyond the extent on every side: min_b and the strides change
+             np.repeat(base[:50], 40, axis=0)]                                              # 40 copies of 50 points
+    steps[0][7] = [np.nan, 0.0, 0.0]
+    steps[3][11] = [0.0, np.inf, 0.0]
+    for k, add in enumerate(steps):
+        st, merged = dev.voxel_merge(api.Cloud(ctx, add), 0.1)
+        assert st == 0 and merged, k
+        host = orc.voxel_pcl(np.concatenate([host, add]), 0.1)[0]
+        got = dev.download()
+        assert got.shape == host.shape and np.array_equal(got, host), k
+    # a cloud that is not voxel-filtered (two points per voxel): keys not strictly ascending -> the full path, same result
+    raw = api.Cloud(ctx, np.concatenate([host[:1000], host[:1000] + np.float32(0.001)]))
+    st, merged = raw.voxel_merge(api.Cloud(ctx, steps[2]), 0.1)
+    assert st == 0 and not merged
+    assert np.array_equal(raw.download(), orc.voxel_pcl(np.concatenate([host[:1000], host[:1000] + np.float32(0.001), steps[2]]), 0.1)[0])
+    # empty pending: the full path (== re-filtering the map)
+    st, merged = dev.voxel_merge(api.Cloud(ctx, np.zeros((0, 3), np.float32)), 0.1)
+    assert not merged and np.array_equal(dev.download(), orc.voxel_pcl(host, 0.1)[0])
