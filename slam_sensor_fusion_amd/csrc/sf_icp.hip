@@ -28,6 +28,7 @@
 #include "sf_common.hpp"
 #include "sf_nn.hpp"
 #include "sf_order.hpp"
+#include "sf_p2p.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -1194,6 +1195,97 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
     else solve_plane(S, rec, n_src, K);
     track_motion(S, To, *boxp);
     if (margin > 0.0f && !S->done) own_check_motion(S, *boxp, margin); // sharded path only (the box of the source batch, computed on the device)
+}
+
+// ------------------------------------------------------------------ sharded step over the P2P transport, two kernels
+// With a P2P communicator the all-reduce needs no kernel of its own: the workgroup that reduces a scan's slab stores the
+// record straight into every rank's exchange region and raises that scan's flag there (k_reduce_publish); the wave that
+// solves a scan waits for the scan's flags, adds the ranks' records in rank order and solves from LDS (k_gather_solve).
+// Per iteration two small kernels instead of three (reduce / all-reduce / solve), and no 148 bytes of scratch per lane for the
+// record.  Protocol, fences and failure behaviour as k_p2p_allreduce (sf_shard.cpp); flags are per scan (sf_p2p.hpp).
+template <int MODE>
+__global__ __launch_bounds__(RBLK) void k_reduce_publish(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, const uint32_t *__restrict__ own_off, int qpl,
+                                                         sf::P2pView v)
+{
+    constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
+    const int b = blockIdx.x, tid = (int)threadIdx.x, R = v.peers.nranks, me = v.peers.rank, par = (int)(v.seq & 1ull);
+    __shared__ double rec[REC_STRIDE];
+    __shared__ int dead;
+    unsigned char *mine = v.peers.region[me];
+    if (tid == 0) dead = __hip_atomic_load(sf::p2p_abort(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 1 : 0;
+    if (st[b].done) { // keep the exchange's shape: contribute zeros
+        if (tid < REC_STRIDE) rec[tid] = 0.0;
+        __syncthreads();
+    } else {
+        const int rows = own_off ? (int)((own_off[b + 1] - own_off[b] + BLK * qpl - 1) / (BLK * qpl)) : nblocks;
+        reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, rows, rec); // (ends with a barrier)
+    }
+    if (dead) return; // the communicator is poisoned: k_gather_solve reports it
+    if (tid < REC_STRIDE * R) {
+        const int c = tid & (REC_STRIDE - 1), r = tid / REC_STRIDE;
+        __hip_atomic_store(sf::p2p_slot(v.peers.region[r], par, me, R, v.max_count) + (size_t)b * REC_STRIDE + c, rec[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (tid < R) __hip_atomic_store(sf::p2p_sflag(v.peers.region[tid], b, me), v.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_gather_solve(IcpState *__restrict__ st, int n_src, int K, const ScanBox *__restrict__ boxp, float margin, sf::P2pView v)
+{
+    constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
+    const int b = blockIdx.x, lane = (int)threadIdx.x, R = v.peers.nranks, me = v.peers.rank, par = (int)(v.seq & 1ull);
+    __shared__ double rec[REC_STRIDE];
+    __shared__ int verdict;
+    unsigned char *mine = v.peers.region[me];
+    if (lane == 0) verdict = __hip_atomic_load(sf::p2p_abort(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 2 : 0;
+    __syncthreads();
+    if (verdict == 0 && lane < R) {
+        const long long t0 = wall_clock64();
+        int bad = 0;
+        while (__hip_atomic_load(sf::p2p_sflag(mine, b, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < v.seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__hip_atomic_load(sf::p2p_abort(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { bad = 2; break; }
+            if (wall_clock64() - t0 > v.spin_ticks) { bad = 1; break; }
+        }
+        if (bad) atomicMax(&verdict, bad);
+    }
+    if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    IcpState *S = st + b;
+    if (verdict != 0) { // poison every region this rank reaches, report, stop the scan
+        if (lane < R) __hip_atomic_store(sf::p2p_abort(v.peers.region[lane]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) {
+            if (__hip_atomic_load(v.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) __hip_atomic_store(v.status, (uint32_t)verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            S->done = 1;
+        }
+        return;
+    }
+    if (lane < REC_STRIDE) { // the ranks' records in rank order: the same bits on every rank
+        double s = 0.0;
+        for (int r = 0; r < R; ++r) s += __hip_atomic_load(sf::p2p_slot(mine, par, r, R, v.max_count) + (size_t)b * REC_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        rec[lane] = lane < NREC ? s : 0.0;
+    }
+    __syncthreads();
+    if (lane == 0 && !S->done) {
+#pragma unroll
+        for (int c = 0; c < NREC; ++c) S->rec[c] = rec[c];
+        double To[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) To[i] = S->T[i];
+        if (MODE == 1) solve_o3d(S, rec, n_src, 0, K);
+        else solve_plane(S, rec, n_src, K);
+        track_motion(S, To, *boxp);
+        if (margin > 0.0f && !S->done) own_check_motion(S, *boxp, margin);
+    }
 }
 
 // ------------------------------------------------------------------ the per-scan source in one pass
@@ -2855,6 +2947,35 @@ bool any_stale(const sf_icp *icp)
 
 } // namespace
 
+namespace {
+// one iteration of the sharded loop over a P2P communicator: NN + slab rows, reduce + publish, gather + solve
+int shard_step_p2p(sf_icp *icp, int mode, int first, const sf::P2pView &view)
+{
+    SF_HIP(hipSetDevice(icp->ctx->device));
+    icp->last_mode = mode;
+    icp->last_fused = false;
+    if (first == 1) SF_TRY(launch_state_init(icp));
+    if (first) SF_TRY(shard_build(icp, first == 2));
+    hipStream_t s = icp->ctx->stream;
+    IcpState *st = icp->state.as<IcpState>();
+    const int nb = icp->own_nblocks, B = icp->batch, K = icp->prm.num_iters;
+    if (mode == SF_ICP_O3D_P2P) launch_nn_red<1>(icp, true);
+    else launch_nn_red<2>(icp, true);
+    {
+        ProfScope ps(icp, SF_PROF_REDUCE);
+        if (mode == SF_ICP_O3D_P2P) hipLaunchKernelGGL(k_reduce_publish<1>, dim3(B), dim3(RBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qpl, view);
+        else hipLaunchKernelGGL(k_reduce_publish<2>, dim3(B), dim3(RBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qpl, view);
+    }
+    {
+        ProfScope ps(icp, SF_PROF_COLLECTIVE); // the wait for the peers' records AND the solve
+        if (mode == SF_ICP_O3D_P2P) hipLaunchKernelGGL(k_gather_solve<1>, dim3(B), dim3(64), 0, s, st, (int)icp->n, K, icp->d_box.as<ScanBox>(), icp->own_margin, view);
+        else hipLaunchKernelGGL(k_gather_solve<2>, dim3(B), dim3(64), 0, s, st, (int)icp->n, K, icp->d_box.as<ScanBox>(), icp->own_margin, view);
+    }
+    SF_HIP(hipGetLastError());
+    return SF_OK;
+}
+} // namespace
+
 extern "C" int sf_icp_align_sharded_async(sf_icp *icp, int mode, sf_comm *comm, int first)
 {
     SF_TRY(check_ready(icp, mode));
@@ -2864,6 +2985,13 @@ extern "C" int sf_icp_align_sharded_async(sf_icp *icp, int mode, sf_comm *comm, 
     const int steps = sharded_steps(icp, mode);
     int rc = SF_OK;
     for (int k = 0; k < steps && rc == SF_OK; ++k) {
+        sf::P2pView view;
+        const int p2p = sf::comm_p2p_begin(comm, (int64_t)REC_STRIDE * icp->batch, &view);
+        if (p2p < 0) { rc = p2p; break; }
+        if (p2p == 1) { // P2P: the reduce kernel publishes, the solve kernel gathers (two kernels per iteration, no all-reduce of its own)
+            rc = shard_step_p2p(icp, mode, k == 0 ? first : 0, view);
+            continue;
+        }
         rc = sf_icp_step_begin(icp, mode, k == 0 ? first : 0);
         if (rc == SF_OK) {
             ProfScope ps(icp, SF_PROF_COLLECTIVE);

@@ -8,6 +8,7 @@
 // and under Python that is the pair the torch wheel ships (torch is only the launcher / rendezvous here), while a
 // C++ host uses /opt/rocm's.  sf_comm_load_rccl names the library; the default is whatever the process has loaded.
 #include "sf_common.hpp"
+#include "sf_p2p.hpp"
 
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -93,15 +94,8 @@ const char *rccl_error(int rc) { return g_rccl.error_string ? g_rccl.error_strin
 // device (how the sharded loop is tested on a one-GPU box) and 8 ranks over xGMI.
 namespace {
 
-constexpr int P2P_MAX_RANKS = 16;
+using namespace sf; // layout constants and device helpers: sf_p2p.hpp
 constexpr uint32_t P2P_MAGIC = 0x32504653u; // "SFP2"
-constexpr size_t P2P_LINE = 128;
-constexpr int P2P_BLK = 1024;
-constexpr int P2P_CHUNK = 2048;      // doubles one workgroup carries: a batch's records are split over count / 2048 workgroups,
-constexpr int P2P_MAX_CHUNKS = 64;   // each with flags of its own (a 512-scan batch at 8 GPUs is 16 384 doubles = 8 chunks)
-constexpr size_t P2P_FLAGS_OFF = 0;                                                       // uint64 flag[chunk][r] at (chunk * 16 + r) * 128
-constexpr size_t P2P_ABORT_OFF = P2P_LINE * P2P_MAX_RANKS * P2P_MAX_CHUNKS;               // uint32
-constexpr size_t P2P_SLOTS_OFF = P2P_ABORT_OFF + 2 * P2P_LINE;                            // double slot[2][nranks][max_count]
 
 struct P2pHandle { // SF_COMM_P2P_HANDLE_BYTES: what the launcher hands round
     uint32_t magic;
@@ -114,18 +108,6 @@ struct P2pHandle { // SF_COMM_P2P_HANDLE_BYTES: what the launcher hands round
     char pad[128 - 48 - sizeof(hipIpcMemHandle_t)];
 };
 static_assert(sizeof(P2pHandle) == SF_COMM_P2P_HANDLE_BYTES, "handle blob size");
-
-struct P2pPeers { unsigned char *region[P2P_MAX_RANKS]; int nranks, rank; };
-
-__device__ __forceinline__ unsigned long long *p2p_flag(unsigned char *region, int chunk, int r)
-{
-    return reinterpret_cast<unsigned long long *>(region + P2P_FLAGS_OFF + ((size_t)chunk * P2P_MAX_RANKS + (size_t)r) * P2P_LINE);
-}
-__device__ __forceinline__ uint32_t *p2p_abort(unsigned char *region) { return reinterpret_cast<uint32_t *>(region + P2P_ABORT_OFF); }
-__device__ __forceinline__ double *p2p_slot(unsigned char *region, int parity, int r, int nranks, int64_t max_count)
-{
-    return reinterpret_cast<double *>(region + P2P_SLOTS_OFF) + ((size_t)parity * (size_t)nranks + (size_t)r) * (size_t)max_count;
-}
 
 // status word (pinned host memory): 0 ok, 1 timed out waiting for a peer, 2 aborted by a peer / the host.
 // grid.x = chunks of P2P_CHUNK doubles; a workgroup carries its chunk through publish / signal / wait / sum on its own flags
@@ -481,6 +463,23 @@ extern "C" int sf_comm_size(const sf_comm *c, int *nranks, int *rank)
 
 namespace sf {
 sf_ctx *comm_ctx(const sf_comm *c) { return c ? c->ctx : nullptr; }
+int comm_p2p_begin(sf_comm *c, int64_t count, P2pView *v)
+{
+    if (!c || c->kind != SF_COMM_P2P) return 0;
+    SF_CHECK(c->connected, SF_ERR_STATE, "P2P communicator is not connected (sf_comm_p2p_connect / sf_comm_p2p_rendezvous)");
+    SF_CHECK(count <= c->max_count && count / 32 <= P2P_MAX_SCANS, SF_ERR_INVALID, "collective of %lld doubles exceeds the communicator's capacity %lld", (long long)count,
+             (long long)c->max_count);
+    SF_TRY(p2p_status_to_rc(c)); // poisoned: do not enqueue more
+    c->seq += 1;
+    c->n_collectives += 1;
+    v->peers = c->peers;
+    v->max_count = c->max_count;
+    v->seq = c->seq;
+    v->spin_ticks = (long long)(c->timeout_s * 1e8);
+    v->status = c->status;
+    return 1;
+}
+
 // in-place sum of `count` float64 on the communicator's context stream (enqueue only)
 int comm_allreduce_f64(sf_comm *c, void *d_buf, int64_t count)
 {
