@@ -541,6 +541,62 @@ def test_nn_reuse_fuzz(api, ctx, synth):
                 assert np.array_equal(a["T64"], b["T64"], equal_nan=True) and (a["rmse"] == b["rmse"] or (np.isnan(a["rmse"]) and np.isnan(b["rmse"]))), (trial, mode)
 
 
+def test_nn_reuse_fuzz_wide_scans(api, ctx, synth):
+    """The same property for scans above 131 072 points, which take the other summation order (two queries per lane, one
+    wave reduction) and, from the fifth launch on, the wave-level verify path with all loads in flight: clustered,
+    duplicated, lattice and planar maps with extents up to 40 m (the motion bound's lever arm), rotations of several
+    degrees in the start poses; reuse on == reuse off in every bit, graph replay == plain launches."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("SF_FUZZ_SEED", "78")))
+    for trial in range(max(4, int(os.environ.get("SF_FUZZ_TRIALS", "24")) // 6)):
+        kind = trial % 4
+        n_map = int(rng.integers(100_000, 400_000))
+        ext = float(rng.choice([6.0, 12.0, 20.0]))
+        if kind == 0:
+            m = rng.uniform(-ext, ext, (n_map, 3)) * [1.0, 1.0, 0.2]
+        elif kind == 1:
+            c = rng.uniform(-ext, ext, (400, 3))
+            m = c[rng.integers(0, 400, n_map)] + rng.normal(0, 0.2, (n_map, 3))
+            k7 = len(m[1::7])
+            m[::7][:k7] = m[1::7]
+        elif kind == 2:
+            m = np.round(rng.uniform(-ext, ext, (n_map, 3)) * [1.0, 1.0, 0.2] * 8) / 8
+        else:
+            m = rng.uniform(-ext, ext, (n_map, 3))
+            m[: n_map // 2, 2] = 0.0
+            m[n_map // 2:, 0] = 2.0
+        m = m.astype(np.float32)
+        mp = api.Map(ctx, api.Cloud(ctx, m), float(rng.choice([0.0, 0.25, 0.5])))
+        mp.estimate_normals(0.4)
+        n_scan = int(rng.integers(131_073, 160_000))
+        scans, inits = [], []
+        for s in range(3):
+            T = synth.make_T(rng.normal(0, 0.08 if s else 0.01, 3), rng.normal(0, 0.6 if s else 0.05, 3))
+            idx = rng.integers(0, len(m), n_scan)
+            p = m[idx].astype(np.float64) + rng.normal(0, 0.02, (n_scan, 3))
+            Ti = np.linalg.inv(T)
+            scans.append((p @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32))
+            inits.append(np.eye(4))
+        scans = np.stack(scans)
+        for mode in ("p2plane", "o3d_p2p"):
+            thr = float(rng.choice([0.3, 0.5, 1.0]))
+            res = []
+            for reuse, graph in ((False, False), (True, False), (True, True)):
+                icp = api.Icp(ctx, thr, 12, 0.05, 1e-5)
+                icp.set_target(mp)
+                icp.set_nn_reuse(reuse)
+                icp.use_graph(graph)
+                icp.set_query_order("cell" if trial % 2 else "as_given")
+                icp.set_source_batch(scans)
+                icp.set_initial_batch(np.stack(inits))
+                res.append(icp.align_batch(mode))
+                icp.close()
+            for other in res[1:]:
+                for a, b in zip(res[0], other):
+                    assert a["n_corr"] == b["n_corr"] and a["iterations"] == b["iterations"] and a["flags"] == b["flags"], (trial, mode)
+                    assert np.array_equal(a["T64"], b["T64"], equal_nan=True) and (a["rmse"] == b["rmse"] or (np.isnan(a["rmse"]) and np.isnan(b["rmse"]))), (trial, mode)
+
+
 def test_switches_between_alignments_with_graph_replay(api, ctx, synth, small_world):
     """One sf_icp object, hipGraph replay on, switches flipped between alignments: the captured
     launch list carries the neighbour-cache and query-array pointers, so a flip must re-capture."""
