@@ -927,6 +927,51 @@ __global__ __launch_bounds__(256) void k_order_gather(const float4 *__restrict__
 
 struct ScanBox { float lo[3], hi[3]; };
 
+// bounding box of the finite points of every scan of the batch (SoA, scan b at [b * n, b * n + n)): a grid of (BOX_PARTS, batch)
+// workgroups leaves partial boxes, one more launch folds them.  A scan without a finite point gets the empty box at the origin.
+constexpr int BOX_PARTS = 32;
+__global__ __launch_bounds__(256) void k_scan_boxes_partial(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, int n, ScanBox *__restrict__ part)
+{
+    const int b = blockIdx.y, p = blockIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const size_t base = (size_t)b * n;
+    for (int i = p * 256 + (int)threadIdx.x; i < n; i += BOX_PARTS * 256) {
+        const float v[3] = {x[base + i], y[base + i], z[base + i]};
+        if (isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2])) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], v[d]); hi[d] = fmaxf(hi[d], v[d]); }
+        }
+    }
+    __shared__ float s[BLK / 64][6];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64)); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { s[threadIdx.x >> 6][d] = lo[d]; s[threadIdx.x >> 6][3 + d] = hi[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        part[(size_t)b * BOX_PARTS + p].lo[d] = fminf(fminf(s[0][d], s[1][d]), fminf(s[2][d], s[3][d]));
+        part[(size_t)b * BOX_PARTS + p].hi[d] = fmaxf(fmaxf(s[0][3 + d], s[1][3 + d]), fmaxf(s[2][3 + d], s[3][3 + d]));
+    }
+}
+
+__global__ void k_scan_boxes_final(const ScanBox *__restrict__ part, int batch, ScanBox *__restrict__ boxes)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    ScanBox r;
+    for (int d = 0; d < 3; ++d) { r.lo[d] = INFINITY; r.hi[d] = -INFINITY; }
+    for (int p = 0; p < BOX_PARTS; ++p)
+        for (int d = 0; d < 3; ++d) { r.lo[d] = fminf(r.lo[d], part[(size_t)b * BOX_PARTS + p].lo[d]); r.hi[d] = fmaxf(r.hi[d], part[(size_t)b * BOX_PARTS + p].hi[d]); }
+    if (!(r.lo[0] <= r.hi[0])) { for (int d = 0; d < 3; ++d) r.lo[d] = r.hi[d] = 0.0f; }
+    boxes[b] = r;
+}
+
 __device__ __forceinline__ unsigned own_lane_rank(unsigned long long ballot)
 {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0u));
@@ -1154,7 +1199,7 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve(IcpState *__restrict__ st
         for (int i = 0; i < 12; ++i) To[i] = S->T[i];
         if (MODE == 1) solve_o3d(S, rec, n_src, k, K);
         else solve_plane(S, rec, n_src, K);
-        track_motion(S, To, *boxp);
+        track_motion(S, To, boxp[b]);
     }
 }
 
@@ -1193,8 +1238,8 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
     for (int i = 0; i < 12; ++i) To[i] = S->T[i];
     if (MODE == 1) solve_o3d(S, rec, n_src, 0, K);
     else solve_plane(S, rec, n_src, K);
-    track_motion(S, To, *boxp);
-    if (margin > 0.0f && !S->done) own_check_motion(S, *boxp, margin); // sharded path only (the box of the source batch, computed on the device)
+    track_motion(S, To, boxp[b]);
+    if (margin > 0.0f && !S->done) own_check_motion(S, boxp[b], margin); // sharded path only (the scan's own box, computed on the device)
 }
 
 // ------------------------------------------------------------------ sharded step over the P2P transport, two kernels
@@ -1283,8 +1328,8 @@ __global__ __launch_bounds__(64) void k_gather_solve(IcpState *__restrict__ st, 
         for (int i = 0; i < 12; ++i) To[i] = S->T[i];
         if (MODE == 1) solve_o3d(S, rec, n_src, 0, K);
         else solve_plane(S, rec, n_src, K);
-        track_motion(S, To, *boxp);
-        if (margin > 0.0f && !S->done) own_check_motion(S, *boxp, margin);
+        track_motion(S, To, boxp[b]);
+        if (margin > 0.0f && !S->done) own_check_motion(S, boxp[b], margin);
     }
 }
 
@@ -1882,6 +1927,7 @@ struct sf_icp {
     float own_margin = 1.0f;                          // sf_icp_set_shard_margin
     int own_nblocks = 1;                              // workgroups per scan on the sharded path (largest scan)
     sf::DevBuf d_box;                        // sf::MinMaxDev: bounding box of the source batch (finite points), left on the device
+    sf::DevBuf d_boxes, d_box_parts;         // ScanBox per scan (motion bound of the reuse certificate, owned-array margin), and the partial boxes of their reduction
     sf::DevBuf stage;                        // persistent upload staging of sf_icp_set_source* (AoS)
     int last_mode = 0;
     // REF_CPP in one launch (k_ref_fused)
@@ -2057,6 +2103,13 @@ int icp_set_source_device_aos(sf_icp *icp, const float *d_aos, int64_t n, int ba
     static_assert(sizeof(ScanBox) <= sizeof(sf::MinMaxDev), "ScanBox is the head of MinMaxDev");
     SF_TRY(icp->d_box.reserve(sizeof(sf::MinMaxDev)));
     SF_TRY(sf::cloud_minmax_enqueue(icp->ctx, d_aos, total, icp->d_box.as<sf::MinMaxDev>()));
+    // ... and of every scan on its own: what moves a scan's points is bounded by ITS box (a batch of 10 m scans spread over a
+    // 100 m map has a 100 m box and every rotation a 50 m lever arm)
+    SF_TRY(icp->d_boxes.reserve(sizeof(ScanBox) * (size_t)std::max(batch, 1)));
+    SF_TRY(icp->d_box_parts.reserve(sizeof(ScanBox) * BOX_PARTS * (size_t)std::max(batch, 1)));
+    hipLaunchKernelGGL(k_scan_boxes_partial, dim3(BOX_PARTS, (unsigned)std::max(batch, 1)), dim3(256), 0, icp->ctx->stream, soa(icp->X0, icp->plane, 0), soa(icp->X0, icp->plane, 1),
+                       soa(icp->X0, icp->plane, 2), (int)n, icp->d_box_parts.as<ScanBox>());
+    hipLaunchKernelGGL(k_scan_boxes_final, dim3(nblk(std::max(batch, 1), 64)), dim3(64), 0, icp->ctx->stream, icp->d_box_parts.as<ScanBox>(), std::max(batch, 1), icp->d_boxes.as<ScanBox>());
     icp->have_source = true;
     return SF_OK;
 }
@@ -2107,7 +2160,7 @@ sf_icp::GraphKey graph_key_now(const sf_icp *icp, int mode)
     k.map = (const void *)icp->map;
     k.map_generation = icp->map->generation;
     k.max_corr = icp->prm.max_corr; k.accept = icp->prm.accept; k.eps = icp->prm.eps;
-    const sf::DevBuf *bufs[] = {&icp->X0, &icp->X0r, &icp->X, &icp->Xq, &icp->qcache, &icp->corr, &icp->state, &icp->partials, &icp->d_box, &icp->n_dev,
+    const sf::DevBuf *bufs[] = {&icp->X0, &icp->X0r, &icp->X, &icp->Xq, &icp->qcache, &icp->corr, &icp->state, &icp->partials, &icp->d_box, &icp->d_boxes, &icp->n_dev,
                                 &icp->map->pts4, &icp->map->nrm4, &icp->map->cell_start, &icp->map->d_window};
     k.epochs = (uint64_t)icp->plane;
     for (const sf::DevBuf *b : bufs) k.epochs = k.epochs * 1000003ull + b->epoch;
@@ -2194,12 +2247,12 @@ int enqueue_align(sf_icp *icp, int mode)
     if (mode == SF_ICP_O3D_P2P) {
         for (int k = 0; k <= K; ++k) {
             launch_nn_red<1>(icp);
-            hipLaunchKernelGGL(k_reduce_solve<1>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K, icp->d_box.as<ScanBox>());
+            hipLaunchKernelGGL(k_reduce_solve<1>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K, icp->d_boxes.as<ScanBox>());
         }
     } else if (mode == SF_ICP_P2PLANE) {
         for (int k = 0; k < K; ++k) {
             launch_nn_red<2>(icp);
-            hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K, icp->d_box.as<ScanBox>());
+            hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K, icp->d_boxes.as<ScanBox>());
         }
     } else {
         SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(icp->plane, 1)));
@@ -2464,7 +2517,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     if (icp->inits_ev) { e = hipEventDestroy(icp->inits_ev); (void)e; }
     if (icp->h_inits) { e = hipHostFree(icp->h_inits); (void)e; }
     icp->X0.release(); icp->X0r.release(); icp->qcache.release(); icp->X.release(); icp->Xq.release(); icp->qkeys.release(); icp->qkeys2.release(); icp->qidx.release(); icp->qidx2.release(); icp->corr.release(); icp->bar.release(); if (icp->h_pin) { hipError_t eh = hipHostFree(icp->h_pin); (void)eh; icp->h_pin = nullptr; } icp->state.release(); icp->d_inits.release();
-    icp->n_dev.release(); icp->nn_stats.release(); icp->d_box.release(); icp->stage.release(); icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release(); icp->own_keep.release();
+    icp->n_dev.release(); icp->nn_stats.release(); icp->d_box.release(); icp->d_boxes.release(); icp->d_box_parts.release(); icp->stage.release(); icp->partials.release(); icp->xchg_own.release(); icp->own_idx.release(); icp->own_blk.release(); icp->own_count.release(); icp->own_off.release(); icp->own_keep.release();
     if (icp->own_map) sf_map_destroy(icp->own_map);
     if (icp->own_cloud) sf_cloud_destroy(icp->own_cloud);
     sf_ctx *ctx = icp->ctx;
@@ -2883,9 +2936,9 @@ extern "C" int sf_icp_step_end(sf_icp *icp, int mode, int last)
     const int K = icp->prm.num_iters;
     ProfScope ps(icp, SF_PROF_SOLVE);
     if (mode == SF_ICP_O3D_P2P)
-        hipLaunchKernelGGL(k_solve_only<1>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->d_box.as<ScanBox>(), icp->shard ? icp->own_margin : 0.0f);
+        hipLaunchKernelGGL(k_solve_only<1>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->d_boxes.as<ScanBox>(), icp->shard ? icp->own_margin : 0.0f);
     else
-        hipLaunchKernelGGL(k_solve_only<2>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->d_box.as<ScanBox>(), icp->shard ? icp->own_margin : 0.0f);
+        hipLaunchKernelGGL(k_solve_only<2>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->d_boxes.as<ScanBox>(), icp->shard ? icp->own_margin : 0.0f);
     SF_HIP(hipGetLastError());
     return SF_OK;
 }
@@ -2968,8 +3021,8 @@ int shard_step_p2p(sf_icp *icp, int mode, int first, const sf::P2pView &view)
     }
     {
         ProfScope ps(icp, SF_PROF_COLLECTIVE); // the wait for the peers' records AND the solve
-        if (mode == SF_ICP_O3D_P2P) hipLaunchKernelGGL(k_gather_solve<1>, dim3(B), dim3(64), 0, s, st, (int)icp->n, K, icp->d_box.as<ScanBox>(), icp->own_margin, view);
-        else hipLaunchKernelGGL(k_gather_solve<2>, dim3(B), dim3(64), 0, s, st, (int)icp->n, K, icp->d_box.as<ScanBox>(), icp->own_margin, view);
+        if (mode == SF_ICP_O3D_P2P) hipLaunchKernelGGL(k_gather_solve<1>, dim3(B), dim3(64), 0, s, st, (int)icp->n, K, icp->d_boxes.as<ScanBox>(), icp->own_margin, view);
+        else hipLaunchKernelGGL(k_gather_solve<2>, dim3(B), dim3(64), 0, s, st, (int)icp->n, K, icp->d_boxes.as<ScanBox>(), icp->own_margin, view);
     }
     SF_HIP(hipGetLastError());
     return SF_OK;
