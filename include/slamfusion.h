@@ -137,6 +137,9 @@ int sf_cloud_voxel_downsample(sf_cloud *c, double leaf, int flavour, int *status
  * the two calls whenever the preconditions do not hold (map keys not strictly ascending under the union's geometry, index
  * overflow, an empty side); *merged (may be NULL) says which way it went.  Both clouds on the same context. */
 int sf_cloud_voxel_merge(sf_cloud *map, sf_cloud *pending, double leaf, int *status_flags, int *merged);
+/* maps smaller than this take the full path inside sf_cloud_voxel_merge (default 4 000 000 points: below, the full filter is as fast);
+ * returns the previous value, n < 0 only reads it */
+int sf_cloud_voxel_merge_min_points(int64_t n);
 /* introspection for parity tests: per-input-point voxel ids of the LAST downsample
  * (PCL: int32 linear index, -1 for non-finite; O3D: int32 i,j,k triplets) and the ids /
  * float64 means of the output voxels (O3D flavour keeps float64 means). */

@@ -92,6 +92,11 @@ def load_library():
     return lib
 
 
+def voxel_merge_min_points(n=-1):
+    """Map size from which Cloud.voxel_merge merges instead of re-filtering (returns the previous value; n < 0 only reads it)."""
+    return int(load_library().sf_cloud_voxel_merge_min_points(C.c_int64(n)))
+
+
 def kernel_source_hash():
     """sha256[:16] of the sources the dominant kernel (k_nn_red / k_ref_nn) is compiled from.  profiles/*_traffic.json
     carry the hash of the build their counters were taken on; bench.py only quotes them while it still matches."""

@@ -35,6 +35,7 @@ def test_1000_scan_stream_with_imu_ekf_and_map_growth(api, ctx, orc, synth):
     known = kc.download()
     lla0 = np.array([[-22.9068, -43.1729, 12.0]])
     mtg = api.map_T_global(lla0, np.zeros(1, np.float32))
+    prev_min = api.voxel_merge_min_points(0)                             # this map stays below the size from which merging pays: merge anyway, it is what is checked here
     flow = ImuEkfMappingFlow(ctx, known, mtg, altitude_table=lla0, grow_every=10)
     flow.coarse_alignment_complete_ = True
     stream = synth.make_stream(N_SCANS)
@@ -85,6 +86,7 @@ def test_1000_scan_stream_with_imu_ekf_and_map_growth(api, ctx, orc, synth):
     print("config 4: median / p99 / max translation error %.3f / %.3f / %.3f m, rotation %.4f rad, %d growth steps (%d checked), map %d -> %d points"
           % (np.median(errs), np.quantile(errs, 0.99), errs.max(), np.median(rot_errs), flow.growths_, checked, n_map[0], n_map[-1]))
     assert flow.growths_ == (N_SCANS - 1) // 10 and checked == len(check_at)
+    api.voxel_merge_min_points(prev_min)
     assert flow.merges_ >= flow.growths_ - 2                             # the growth steps took the merge path (sf_cloud_voxel_merge), bit-equal to the oracle above
     # lock kept over the whole drive, 80 m of it on map the vehicle built itself (the ICP's own stop rule is a 5 cm mean error)
     # (measured: median 1.5 cm, max 4.7 cm after 100 m)

@@ -83,6 +83,7 @@ def test_voxel_merge_equals_append_plus_filter(api, ctx, orc, synth):
     new voxels inside, before and after the map's extent (the bounding box -- hence every linear index -- changes), duplicates
     and non-finite points; and the fall-back when the map is not a filtered cloud."""
     rng = np.random.default_rng(5)
+    prev = api.voxel_merge_min_points(0)                             # (small maps take the full path by default: merge them here)
     base = synth.make_map(300_000)                                   # 17 m x 17 m x 10 m
     host = orc.voxel_pcl(base[base[:, 0] < 0.0], 0.1)[0]
     dev = api.Cloud(ctx, host.copy())
@@ -109,3 +110,6 @@ def test_voxel_merge_equals_append_plus_filter(api, ctx, orc, synth):
     # empty pending: the full path (== re-filtering the map)
     st, merged = dev.voxel_merge(api.Cloud(ctx, np.zeros((0, 3), np.float32)), 0.1)
     assert not merged and np.array_equal(dev.download(), orc.voxel_pcl(host, 0.1)[0])
+    api.voxel_merge_min_points(prev)
+    st, merged = dev.voxel_merge(api.Cloud(ctx, steps[2]), 0.1)       # below the default threshold: the full path, same semantics
+    assert st == 0 and not merged
