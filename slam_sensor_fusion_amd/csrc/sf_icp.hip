@@ -524,7 +524,7 @@ __device__ __forceinline__ bool reuse_certificate(bool valid, float qx, float qy
         if (e > 0.0f) {
             const int32_t jc = __float_as_int(c1.w);
             // e - m_now bounds D - |q - q_then| from below; the float32 roundings of q and q_then are charged here
-            const float reach = e - m_now * 1.000002f - (fabsf(qx) + fabsf(qy) + fabsf(qz) + 1.0f) * 1.3e-7f - 1.0e-6f;
+            const float reach = e - m_now * 1.000002f - (fabsf(qx) + fabsf(qy) + fabsf(qz) + 1.0f) * 1.3e-7f - (e + m_now) * 5.0e-7f - 1.0e-6f; // (the last but one: float32 arithmetic on E and M themselves, whatever their size)
             if (jc >= 0) {
                 const float d2n = sf::l2_simple(qx, qy, qz, c1.x, c1.y, c1.z);
                 if (sqrtf(d2n) * 1.0001f + 1.0e-6f < reach) {
