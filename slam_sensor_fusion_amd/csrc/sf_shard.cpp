@@ -271,8 +271,8 @@ extern "C" int sf_comm_p2p_create(sf_ctx *ctx, int nranks, int rank, int64_t max
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, c->region_bytes, hipDeviceMallocFinegrained); }
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        delete c;
         sf::set_error("P2P exchange region (%zu bytes, uncached): %s", c->region_bytes, hipGetErrorString(e));
+        delete c;
         return SF_ERR_NOMEM;
     }
     c->region = static_cast<unsigned char *>(p);
