@@ -548,6 +548,40 @@ def main():
         strong = {"value": args.batch * k_s / float(ts.item()), "scans_in_flight": args.batch, "ms_per_step": float(ts.item()) / k_s * 1e3}
         routed = keep_routed
 
+    # ---------------- N > 1: the fallback SURVEY §8e names -- REPLICAS: every rank holds the whole map (330 MB: it fits) and registers
+    # its own scans unsharded, no collective at all.  Reported beside the sharded metric, never as it: it says what the node does when
+    # the map fits one GPU, and bounds from above what sharding can reach.
+    replicas = None
+    if routed is not None and world > 1 and args.scan_kind == "whole" and not args.no_extras:
+        full_cloud = api.Cloud(ctx, map_ds)
+        full_map = api.Map(ctx, full_cloud, args.cell)
+        if args.mode == "p2plane":
+            full_map.estimate_normals(normal_radius)
+        per = B // world if args.scaling == "weak" else max(B // world, 1)
+        mine_ = scans[rank * per:(rank + 1) * per] if per * world <= B else scans[:per]
+        rep = api.Icp(ctx, max_dist, iters, 0.05, 1e-5)
+        rep.set_target(full_map)
+        rep.use_graph(not args.no_graph)
+        rep.set_query_order(args.query_order)
+        rep.set_nn_reuse(not args.no_nn_reuse)
+        rep.set_source_batch(mine_)
+        rep.set_initial_batch(None)
+        rep.align_batch_async(args.mode)
+        barrier()
+        k_r = max(3, min(10, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(k_r):
+            rep.align_batch_async(args.mode)
+        barrier()
+        tr = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=ddev)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        rr = rep.fetch_results()
+        terr_r = max(synth.pose_error(r_["T64"], synth.t_true())[0] for r_ in rr)
+        replicas = {"value": per * world * k_r / float(tr.item()), "unit": "scans/s", "scans_in_flight_per_gpu": per, "ms_per_step": float(tr.item()) / k_r * 1e3,
+                    "max_translation_err_vs_truth_m": terr_r,
+                    "what": "replicas, NOT the sharded metric: every rank holds the whole map and registers its own scans unsharded, no collective (SURVEY 8e fallback)"}
+        rep.close()
+
     # ---------------- untimed extra legs: no-reuse throughput, upload-inclusive rate, single-scan latency
     extras = {}
     if routed is None and not args.no_extras:
@@ -815,6 +849,7 @@ def main():
         out["ranks"] = rank_stats
         out["collective"] = coll_info
         out["value_strong"] = strong
+        out["value_replicas"] = replicas
 
     # ---------------- CPU baseline: the oracle (port of the reference path), 1 thread, rank 0, N=1 -- and the parity gate
     if rank == 0 and world == 1 and not sharded_run and not args.no_cpu_baseline:

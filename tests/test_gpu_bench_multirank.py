@@ -45,5 +45,6 @@ def test_bench_two_ranks_on_one_gpu(scan_kind):
         assert r["owned_queries_per_launch"]["min"] > 0.3 * 8 * 140000 / 2 and r["collective_us_mean"]["mean"] > 0 and r["nn_us_mean"]["mean"] > 0
         assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
         assert d["value_strong"]["value"] > 0 and d["value_strong"]["scans_in_flight"] == 4
+        assert d["value_replicas"]["value"] > 0 and d["value_replicas"]["scans_in_flight_per_gpu"] == 4 and d["value_replicas"]["max_translation_err_vs_truth_m"] < 5e-3
     else:                                                              # 10 m scans in a 44 m map: some inside one slab, some across the edge
         assert sum(d["config"]["routing_groups"].values()) == 8

@@ -22,6 +22,7 @@ if j.get("ranks"):
             print("  ", k, v)
     print("   collective", j.get("collective"))
     print("   value_strong", j.get("value_strong"))
+    print("   value_replicas", j.get("value_replicas"))
 if "cpu_baseline" in j:
     print("cpu", j["cpu_baseline"]["value"], j["cpu_baseline"]["sample"][:80])
 for k in ("value_stream_config4",):
