@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--cell", type=float, default=0.25)
     ap.add_argument("--query-order", default="auto", choices=["auto", "as_given", "cell"], help="sf_icp_set_query_order")
     ap.add_argument("--no-nn-reuse", action="store_true", help="sf_icp_set_nn_reuse(0): search every query in every iteration")
+    ap.add_argument("--no-freeze", action="store_true", help="sf_icp_set_freeze(0): every launch of an alignment streams every query (rounds 1-3 up to here)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (no-reuse throughput, upload-inclusive rate, single-scan latency)")
     ap.add_argument("--no-graph", action="store_true")
@@ -194,6 +195,7 @@ def main():
         icp.use_graph(not args.no_graph)
         icp.set_query_order(args.query_order)
         icp.set_nn_reuse(not args.no_nn_reuse)
+        icp.set_freeze(not args.no_freeze)
         return icp
 
     # ---------------- the registration driver of this rank
@@ -460,6 +462,7 @@ def main():
             step()
         torch.cuda.synchronize()
         ms, sq, sw = icp.profile_launches()
+        fz_stats = icp.freeze_stats()
         icp.profile_enable(False)
         icp.use_graph(not args.no_graph)
         per = len(ms) // prof_steps
@@ -468,7 +471,17 @@ def main():
         waves = q_launch / 64.0
         frac_search = sq.mean(0) / q_launch
         searching = frac_search > 0.5 if args.mode != "ref_cpp" else ms.mean(0) > 5e-3
-        prof = dict(per=per, ms=ms.mean(0), frac_search=frac_search, wave_frac=sw.mean(0) / waves, searching=searching, q_launch=q_launch)
+        # frozen pairs (p2plane): launches from FZ_FROM on run k_nn_red_fz -- one freeze launch per scan, then launches that only
+        # touch the active queries.  Labelled from the library's own counts: every scan froze once, at the first chance, and stayed so
+        FZ_FROM = 5
+        kind = np.where(searching, "searching", "verifying").astype(object)
+        fz_clean = fz_stats["froze"] == B and fz_stats["frozen_at_end"] == B and fz_stats["failed"] == 0 and fz_stats["thawed"] == 0
+        if fz_stats["froze"] > 0 and per > FZ_FROM:
+            kind[FZ_FROM:] = "frozen" if fz_clean else "mixed (some scans frozen)"
+            if fz_clean:
+                kind[FZ_FROM] = "freeze"
+        prof = dict(per=per, ms=ms.mean(0), frac_search=frac_search, wave_frac=sw.mean(0) / waves, searching=searching, q_launch=q_launch, kind=kind,
+                    fz=fz_stats, fz_from=FZ_FROM if fz_stats["froze"] > 0 else per)
 
     # ---------------- N > 1: what every rank spent where (HIP events around every phase of the sharded loop, on the stream)
     rank_stats, roof_dist = None, None
@@ -596,6 +609,16 @@ def main():
             torch.cuda.synchronize()
             extras["value_no_reuse"] = B * k / (time.perf_counter() - t1)
             icp.set_nn_reuse(True)
+        if args.mode == "p2plane" and not args.no_nn_reuse and not args.no_freeze:
+            icp.set_freeze(False)
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k):
+                step()
+            torch.cuda.synchronize()
+            extras["value_no_freeze"] = B * k / (time.perf_counter() - t1)
+            icp.set_freeze(True)
         # upload-inclusive: every step uploads its batch from pinned host memory.  Double buffering: the raw H2D copy of
         # batch k+1 runs on a copy stream into one of two staging buffers while batch k is registered on the compute
         # stream, which picks the staged batch up on the device (sf_icp_set_source_batch_device) once its copy event has
@@ -729,7 +752,8 @@ def main():
     a_nn = A_NN_P2PLANE if args.mode == "p2plane" else A_NN_P2P
     roof = None
     if prof is not None:
-        nn_ms = float(prof["ms"].mean())
+        sel_k = np.arange(prof["per"]) < prof["fz_from"]        # the launches of the dominant kernel itself (k_nn_red; from fz_from on: k_nn_red_fz)
+        nn_ms = float(prof["ms"][sel_k].mean())
         cache_b = 32 if args.mode == "p2plane" else 20          # neighbour cache entry: (neighbour, index) + (normal, E) / + E alone
         map_b = len(mp) * (32 if args.mode == "p2plane" else 16) + 4.0 * np.prod(mp.cell_size()[1])   # every point (+ normal) line and the cell table once
         sel_s, sel_v = prof["searching"], ~prof["searching"]
@@ -761,7 +785,7 @@ def main():
             traffic_src = "profiles/%s (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ by request size, separate passes; source hash %s matches this build)" % (
                 "r03_traffic.json" if not args.no_nn_reuse else "r03_search_traffic.json", src_hash)
             valu = tj.get("valu")
-        bytes_launch = traffic if traffic is not None else float(comp.mean())
+        bytes_launch = traffic if traffic is not None else float(comp[sel_k].mean())
         achieved = bytes_launch / (nn_ms * 1e-3) / 1e9 if nn_ms > 0 else 0.0
 
         def phase(sel):
@@ -780,10 +804,12 @@ def main():
                 # the SURVEY §8(d) figure under its own name: 742 / 754 algorithmic bytes per query-iteration x queries per launch / average launch
                 # duration / peak.  It exceeds 1 because most searches are proven unnecessary and the rest are pruned and shared in L2
                 "sec8d_frac": prof["q_launch"] * a_nn / (nn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "kernel": "k_ref_nn" if args.mode == "ref_cpp" else "k_nn_red", "avg_launch_ms": nn_ms, "launches_per_alignment": int(prof["per"]),
+                "kernel": "k_ref_nn" if args.mode == "ref_cpp" else "k_nn_red", "avg_launch_ms": nn_ms, "launches_per_alignment": int(sel_k.sum()),
+                "launches_per_alignment_all_kernels": int(prof["per"]),
                 "queries_per_launch": prof["q_launch"],
-                "phases": {"searching": phase(sel_s), "verifying": phase(sel_v)},
+                "phases": {"searching": phase(sel_s & sel_k), "verifying": phase(sel_v & sel_k)},
                 "per_launch_us": [round(float(v) * 1e3, 1) for v in prof["ms"]],
+                "per_launch_kind": [str(v) for v in prof["kind"]],
                 "per_launch_queries_searching_frac": [round(float(v), 4) for v in prof["frac_search"]],
                 "effective_algorithmic": {"bytes_per_query": a_nn, "bytes_per_launch": prof["q_launch"] * a_nn,
                                           "gbs": prof["q_launch"] * a_nn / (nn_ms * 1e-3) / 1e9,
@@ -799,8 +825,23 @@ def main():
             roof["searching_frac"] = {"frac": sj["frac_of_hbm_peak_kernel_trace"], "traffic_bytes_per_launch": sj["traffic_bytes_per_launch"],
                                       "avg_launch_us": sj["avg_launch_ns_kernel_trace"] * 1e-3, "valu_busy_frac": (sj.get("valu") or {}).get("valu_busy_frac"),
                                       "source": "profiles/r03_search_traffic.json: PMC traffic / rocprofv3 kernel-trace duration of launches in which every query searches"}
-        if sel_v.any() and args.mode == "p2plane":   # (the other modes converge early: their later launches return at once)
-            roof["verifying_frac"] = float(comp[sel_v].mean() / (prof["ms"][sel_v].mean() * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        sel_vk = sel_v & sel_k
+        if sel_vk.any() and args.mode == "p2plane":   # (the other modes converge early: their later launches return at once)
+            roof["verifying_frac"] = float(comp[sel_vk].mean() / (prof["ms"][sel_vk].mean() * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        if prof["fz"]["froze"] > 0:
+            # the launches after the dominant kernel's: k_nn_red_fz.  The freeze launch streams what a verifying launch streams (44 B per
+            # query) and forms 96 moment sums per pair instead of 30; a frozen launch touches the active queries only -- its time is the
+            # latency of one search, not traffic: no roofline fraction is claimed for it
+            fzl = np.arange(prof["per"]) >= prof["fz_from"]
+            is_freeze = np.array([k_ == "freeze" for k_ in prof["kind"]])
+            roof["frozen_pairs"] = {
+                "kernel": "k_nn_red_fz", "launches_per_alignment": int(fzl.sum()), "sum_us_per_alignment": float(prof["ms"][fzl].sum() * 1e3),
+                "freeze_launch_us": float(prof["ms"][is_freeze].mean() * 1e3) if is_freeze.any() else None,
+                "freeze_launch_frac_of_hbm_peak": float(comp_verify / (prof["ms"][is_freeze].mean() * 1e-3) / 1e9 / HBM_PEAK_GBS) if is_freeze.any() else None,
+                "frozen_launch_us": float(prof["ms"][fzl & ~is_freeze].mean() * 1e3) if (fzl & ~is_freeze).any() else None,
+                "scans": B, **prof["fz"], "active_queries_frac": prof["fz"]["active_queries"] / float(prof["q_launch"]),
+                "what": "from launch %d on the P2PLANE sums of the pairs certified to stay are evaluated from 96 moments (a polynomial in the pose, float64), "
+                        "the active queries launch by launch; same pairs, sums equal to rounding (tests/test_gpu_freeze.py); --no-freeze / value_no_freeze: without" % (prof["fz_from"] + 1)}
 
     scans_total = B * args.steps
     value = scans_total / elapsed
@@ -818,6 +859,7 @@ def main():
         "ms_per_icp_iter_batch": ms_per_step / nn_per_scan,
         "single_scan_latency_ms": extras.get("single_scan_latency_ms"),
         "value_no_reuse": extras.get("value_no_reuse"),
+        "value_no_freeze": extras.get("value_no_freeze"),
         "value_upload_inclusive": extras.get("value_upload_inclusive"),
         "value_32_in_flight": extras.get("value_32_in_flight"),
         "value_stream_config4": extras.get("value_stream_config4"),
@@ -830,9 +872,11 @@ def main():
                                % (n_scan // 1000, "drawn from the whole map" if args.scan_kind == "whole" else "10 m neighbourhoods", args.map_points / 1e6, n_map, iters,
                                   args.mode, "lazy re-search (reference rule)" if args.mode == "ref_cpp" else
                                   ("exact NN result every iter; neighbour reuse %s" % ("off: every query searches in every iteration" if args.no_nn_reuse else
-                                                                                     "on: a query whose neighbour provably cannot have changed skips its search (bit-identical results)"))),
+                                                                                     "on: a query whose neighbour provably cannot have changed skips its search (bit-identical results)" +
+                                                                                     ("" if (args.no_freeze or args.mode != "p2plane") else
+                                                                                      "; once a scan's pairs are certified to stay, their sums come from 96 moments (float64, equal to rounding)")))),
                    "mode": args.mode, "scans_in_flight": B, "scans_in_flight_per_gpu": B // world if args.scaling == "weak" else B, "cell_m": args.cell,
-                   "max_corr_dist_m": max_dist, "nn_reuse": not args.no_nn_reuse, "scan_kind": args.scan_kind,
+                   "max_corr_dist_m": max_dist, "nn_reuse": not args.no_nn_reuse, "frozen_pairs": bool(prof is not None and prof["fz"]["froze"] > 0), "scan_kind": args.scan_kind,
                    "parallelism": ("map sharded into %d x-slabs (+halo); %s; collective: %s"
                                    % (world, "every scan spans every slab: each rank owns 1/%d of every scan's queries, all-reduce of the normal-equation records once per ICP iteration" % world
                                       if args.scan_kind == "whole" else "scans routed to the slabs they touch, one-slab scans registered by one rank without a collective", comm_kind))

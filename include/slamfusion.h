@@ -281,6 +281,20 @@ int sf_icp_set_query_order(sf_icp *icp, int order);
  * search is skipped.  Results are bit-identical with the switch on or off (tested); it only
  * changes how much of the "nearest neighbour every iteration" work has to be redone. */
 int sf_icp_set_nn_reuse(sf_icp *icp, int on);
+/* Frozen pairs (P2PLANE launch list, scans above 131 072 points, neighbour reuse on, whole map, unsharded): once a scan's
+ * pairs are certified to stay as they are while it moves by a guard distance more, one launch forms the 96 moments of
+ * those pairs and the iterations after it evaluate the normal equations from the moments (a polynomial in the pose)
+ * instead of streaming the scan; queries too close to a change stay "active" and are evaluated launch by launch.
+ * Same pairs, same float64 sums up to summation rounding (~1e-13 of a pose).  Default on; no reference counterpart
+ * (the reference searches every point in every iteration, icp_point_to_point.cpp:64-69). */
+int sf_icp_set_freeze(sf_icp *icp, int on);
+/* guard = max(guard_scale x motion of the last pose update, guard_min) [m]; a freeze launch is asked for once that is at most
+ * guard_max (a larger guard means long active lists), at most max_tries times per alignment, from launch index
+ * from_launch (>= 4) on.  Defaults 8, 2e-5, 3e-4, 3, 5. */
+int sf_icp_set_freeze_params(sf_icp *icp, float guard_scale, float guard_min, float guard_max, int max_tries, int from_launch);
+/* of the last batched alignment, summed over its scans: {freeze launches that held, thaws (moved beyond the guard),
+ * freeze launches that did not hold, active queries of the last freeze launch, scans frozen at the end} */
+int sf_icp_freeze_stats(sf_icp *icp, int64_t out[5]);
 
 /* multi-GPU (map tile-sharded along x with halo): this rank only
  * accumulates queries whose TRANSFORMED x lies in [x_lo, x_hi); per iteration

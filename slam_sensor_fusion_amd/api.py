@@ -538,6 +538,19 @@ class Icp:
     def set_nn_reuse(self, on=True):
         _check(self.lib.sf_icp_set_nn_reuse(self.h, C.c_int(int(on))))
 
+    def set_freeze(self, on=True):
+        """Frozen pairs (sf_icp_set_freeze): P2PLANE launch list of wide scans, see include/slamfusion.h."""
+        _check(self.lib.sf_icp_set_freeze(self.h, C.c_int(int(on))))
+
+    def set_freeze_params(self, guard_scale=8.0, guard_min=2.0e-5, guard_max=3.0e-4, max_tries=3, from_launch=5):
+        _check(self.lib.sf_icp_set_freeze_params(self.h, C.c_float(guard_scale), C.c_float(guard_min), C.c_float(guard_max), C.c_int(max_tries), C.c_int(from_launch)))
+
+    def freeze_stats(self):
+        """Of the last batched alignment, summed over its scans (sf_icp_freeze_stats)."""
+        a = (C.c_int64 * 5)()
+        _check(self.lib.sf_icp_freeze_stats(self.h, a))
+        return {"froze": a[0], "thawed": a[1], "failed": a[2], "active_queries": a[3], "frozen_at_end": a[4]}
+
     def set_query_order(self, order="auto"):
         """'auto' | 'as_given' | 'cell' (SF_ORDER_*): the order a scan's points are walked in."""
         _check(self.lib.sf_icp_set_query_order(self.h, C.c_int({"auto": 0, "as_given": 1, "cell": 2}[order])))

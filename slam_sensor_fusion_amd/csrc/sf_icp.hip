@@ -518,6 +518,7 @@ __device__ __forceinline__ bool reuse_certificate(bool valid, float qx, float qy
     hit.px = hit.py = hit.pz = 0.0f;
     hit.lb2 = 0.0f;
     tn = make_float4(0.f, 0.f, 0.f, 0.f); // the neighbour's normal (MODE 2)
+    valid = valid && isfinite(qx) && isfinite(qy) && isfinite(qz); // a non-finite query has no neighbour and needs no search to know it
     bool need = valid;
     seed = sf::NNHit{0.0f, -1, 0.0f, 0.0f, 0.0f, 0.0f};
     if (valid) {
@@ -895,19 +896,30 @@ __global__ __launch_bounds__(sf::ORD_BLK) void k_order_scatter(sf::OrderSrc s, c
 // the ordered ids read coalesced, the queries' float4 records gathered (four in flight per lane), the cell-ordered
 // SoA arrays written coalesced
 constexpr int GATHER_PER_LANE = 4;
-__global__ __launch_bounds__(256) void k_order_gather(const float4 *__restrict__ rec, const uint32_t *__restrict__ idx, int64_t total, float *__restrict__ Xx,
-                                                      float *__restrict__ Xy, float *__restrict__ Xz)
+constexpr int GATHER_TILE = 256 * GATHER_PER_LANE;
+// seg_n > 0: uniform segments of seg_n queries, placed like the ordering kernels (sf::order_block: a scan's tiles on one
+// XCD, whose L2 then holds the scan's 16-byte records while they are gathered); seg_n = 0: one flat range (ragged segments)
+__global__ __launch_bounds__(256) void k_order_gather(const float4 *__restrict__ rec, const uint32_t *__restrict__ idx, int64_t total, int seg_n, int seg_tiles, int nseg,
+                                                      float *__restrict__ Xx, float *__restrict__ Xy, float *__restrict__ Xz)
 {
-    const int64_t base = (int64_t)blockIdx.x * (256 * GATHER_PER_LANE) + threadIdx.x;
+    int64_t base, end = total;
+    if (seg_n > 0) {
+        int b, tile;
+        if (!sf::order_block(seg_tiles, nseg, &b, &tile)) return;
+        base = (int64_t)b * seg_n + (int64_t)tile * GATHER_TILE + threadIdx.x;
+        end = (int64_t)(b + 1) * seg_n;
+    } else {
+        base = (int64_t)blockIdx.x * GATHER_TILE + threadIdx.x;
+    }
     uint32_t o[GATHER_PER_LANE];
     float4 v[GATHER_PER_LANE];
 #pragma unroll
-    for (int k = 0; k < GATHER_PER_LANE; ++k) o[k] = base + 256 * k < total ? idx[base + 256 * k] : 0u;
+    for (int k = 0; k < GATHER_PER_LANE; ++k) o[k] = base + 256 * k < end ? idx[base + 256 * k] : 0u;
 #pragma unroll
     for (int k = 0; k < GATHER_PER_LANE; ++k) v[k] = rec[o[k]];
 #pragma unroll
     for (int k = 0; k < GATHER_PER_LANE; ++k)
-        if (base + 256 * k < total) {
+        if (base + 256 * k < end) {
             Xx[base + 256 * k] = v[k].x;
             Xy[base + 256 * k] = v[k].y;
             Xz[base + 256 * k] = v[k].z;
@@ -1201,6 +1213,492 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve(IcpState *__restrict__ st
         else solve_plane(S, rec, n_src, K);
         track_motion(S, To, boxp[b]);
     }
+}
+
+// ------------------------------------------------------------------ frozen pairs (P2PLANE, wide scans, neighbour reuse on)
+// Once the certificate holds for (nearly) every query, the launches of an alignment re-stream 44 bytes per query only
+// to find that no pair changed -- yet with the pairs fixed the normal equations are a POLYNOMIAL in the pose:
+// with y = R x + t,  r = n.(y - p) = n.y - c  (c = n.p),  J = [y x n; n], every entry of sum J J^T, sum J r, sum r^2
+// and sum |y - p|^2 is a combination of the 96 sums (moments) below with coefficients of degree <= 2 in (R, t).
+// So one launch (the "freeze" launch) forms the moments of all pairs that are certain to stay as they are, and the
+// iterations after it evaluate the sums from the moments in O(1) -- no pass over the scan -- and go on solving and
+// updating the pose exactly as before (float64 throughout: the per-pair terms are float64 products of the same
+// quantities, so the two forms differ by summation rounding only, ~1e-13 of a pose; tested against the launch-by-launch
+// evaluation and against the oracle at its usual 1e-9).
+// "Certain to stay": at the freeze launch a query is FROZEN if its certificate (reuse_certificate) would still hold
+// after the scan has moved by `guard` more than it has so far AND its accepted / rejected status (d2 < thr) cannot
+// change within that motion; everything else is ACTIVE: listed per slab row, taken out of the moments and evaluated
+// launch by launch as before (certificate, search if it fails) by one wave per row.  After every pose update the scan's
+// motion since the freeze (IcpState::motion, the bound the certificate itself uses) is compared with the guard: beyond
+// it the scan thaws -- the next launch treats every query the ordinary way (the cache entries were never touched) --
+// and may freeze again.  The guard is a multiple of the last update's motion: ICP steps shrink geometrically.
+// The pairs and therefore the result do not depend on the guard, only how many queries are active does.
+// Moments are taken in the coordinates of the freeze pose, x = T_f x0 (float64), so (R, t) = T_now T_f^-1 stays near
+// the identity.  Layout (k6(a,b): 00 01 02 11 12 22):
+//   [0,36)  n_c n_f x_d x_e   (6 k6(c,f) + k6(d,e))      [36,54) n_c n_f x_d (36 + 3 k6 + d)     [54,60) n_c n_f
+//   [60,69) c n_a x_d (60 + 3 a + d)   [69,72) c n_a   72 c^2   73 count
+//   [74,80) x_d x_e   [80,83) x_d   [83,92) p_a x_d (83 + 3 a + d)   [92,95) p_a   95 |p|^2
+constexpr int FZ_NMOM = 96;
+constexpr int FZ_CAP = 128;  // active queries one slab row can list (of its 256 * Q)
+struct FreezeState {
+    int mode;         // 0: every query evaluated launch by launch, 1: the next launch is a freeze launch, 2: frozen
+    int tries;        // freeze launches that did not hold (a row's list overflowed) + thaws
+    int froze, thawed;
+    int64_t n_active; // active queries of the last freeze launch
+    float guard;      // motion allowed after the freeze [m]
+    float pad;
+    double motion0;   // IcpState::motion the freeze launch classified with
+    double Tf[12];    // the pose of the freeze launch
+    double mom[FZ_NMOM];
+};
+struct FreezeParams { float guard_scale, guard_min, guard_max; int max_tries; };
+
+__device__ __forceinline__ constexpr int k6a(int k) { return k < 3 ? 0 : (k < 5 ? 1 : 2); }
+__device__ __forceinline__ constexpr int k6b(int k) { return k < 3 ? k : (k < 5 ? k - 2 : 2); }
+__device__ __forceinline__ constexpr int k6(int a, int b) { return a <= b ? (a == 0 ? b : (a == 1 ? 2 + b : 5)) : (b == 0 ? a : (b == 1 ? 2 + a : 5)); }
+
+struct MomIn { double x[3], n[3], p[3], c, w; };
+__device__ __forceinline__ MomIn mom_in(const LanePair &P, bool take)
+{
+    MomIn t;
+    const bool ok = P.ok && take;
+    t.w = ok ? 1.0 : 0.0;
+    t.x[0] = ok ? P.sx : 0.0; t.x[1] = ok ? P.sy : 0.0; t.x[2] = ok ? P.sz : 0.0;
+    t.p[0] = (double)(ok ? P.px : 0.0f); t.p[1] = (double)(ok ? P.py : 0.0f); t.p[2] = (double)(ok ? P.pz : 0.0f);
+    t.n[0] = (double)(ok ? P.tn.x : 0.0f); t.n[1] = (double)(ok ? P.tn.y : 0.0f); t.n[2] = (double)(ok ? P.tn.z : 0.0f);
+    t.c = t.n[0] * t.p[0] + t.n[1] * t.p[1] + t.n[2] * t.p[2];
+    return t;
+}
+template <int I>
+__device__ __forceinline__ double mom_term(const MomIn &t)
+{
+    if constexpr (I < 36) return (t.n[k6a(I / 6)] * t.n[k6b(I / 6)]) * (t.x[k6a(I % 6)] * t.x[k6b(I % 6)]);
+    else if constexpr (I < 54) return (t.n[k6a((I - 36) / 3)] * t.n[k6b((I - 36) / 3)]) * t.x[(I - 36) % 3];
+    else if constexpr (I < 60) return t.n[k6a(I - 54)] * t.n[k6b(I - 54)];
+    else if constexpr (I < 69) return (t.c * t.n[(I - 60) / 3]) * t.x[(I - 60) % 3];
+    else if constexpr (I < 72) return t.c * t.n[I - 69];
+    else if constexpr (I == 72) return t.c * t.c;
+    else if constexpr (I == 73) return t.w;
+    else if constexpr (I < 80) return t.x[k6a(I - 74)] * t.x[k6b(I - 74)];
+    else if constexpr (I < 83) return t.x[I - 80];
+    else if constexpr (I < 92) return t.p[(I - 83) / 3] * t.x[(I - 83) % 3];
+    else if constexpr (I < 95) return t.p[I - 92];
+    else return t.p[0] * t.p[0] + t.p[1] * t.p[1] + t.p[2] * t.p[2];
+}
+template <int H, int K = 0>
+__device__ __forceinline__ void mom_add16(const MomIn &t, double (&v)[16])
+{
+    if constexpr (K < 16) {
+        v[K] += mom_term<16 * H + K>(t);
+        mom_add16<H, K + 1>(t, v);
+    }
+}
+
+// whether the query is certain to keep its pair (and its accepted / rejected status) while the scan moves by at most
+// `guard` more: the certificate of reuse_certificate evaluated at motion m_now + guard with the distance grown by guard
+__device__ __forceinline__ bool stays_frozen(const QueryIn &q, float thr, float m_now, float guard)
+{
+    if (!q.valid) return true; // no query here: nothing to evaluate, ever
+    if (!(isfinite(q.qx) && isfinite(q.qy) && isfinite(q.qz))) return true; // never has a pair (the search takes no non-finite query)
+    if (!(q.e > 0.0f)) return false;
+    const float m = m_now + guard * 1.000002f;
+    const float reach = q.e - m * 1.000002f - (fabsf(q.qx) + fabsf(q.qy) + fabsf(q.qz) + 3.0f * guard + 1.0f) * 2.6e-7f - (q.e + m) * 5.0e-7f - 1.0e-6f;
+    const float rt = sqrtf(thr);
+    const int32_t jc = __float_as_int(q.c1.w);
+    if (jc < 0) return rt * 1.0001f + 1.0e-6f < reach;
+    const float d = sqrtf(sf::l2_simple(q.qx, q.qy, q.qz, q.c1.x, q.c1.y, q.c1.z));
+    if (!((d + guard) * 1.0001f + 1.0e-6f < reach)) return false;
+    const bool stays_in = (d + guard) * 1.0001f + 1.0e-6f < rt * 0.9999f;
+    const bool stays_out = (d - guard) * 0.9999f - 1.0e-6f > rt * 1.0001f;
+    return stays_in || stays_out;
+}
+
+// k_nn_red for the launches that may freeze: P2PLANE, no window, unsharded, Q queries per lane.  Per scan (FreezeState::mode):
+//   0  the ordinary launch (same pairs, same sums, same row as k_nn_red)
+//   1  freeze launch: ordinary pairs; frozen ones into the moment row, active ones into the ordinary row and the row's list
+//   2  frozen: the scan's active queries, FZ_CAP per workgroup (wave 0: certificate, search if it fails), into the first rows; the other workgroups leave
+template <int Q>
+__global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
+                                                   int n, const IcpState *__restrict__ st, float thr, double *__restrict__ partials, int nblocks, float4 *__restrict__ qcache,
+                                                   int64_t cache_n, uint32_t *__restrict__ stats, const FreezeState *__restrict__ fz, double *__restrict__ mom_part,
+                                                   uint32_t *__restrict__ act_cnt, uint16_t *__restrict__ act_ids, const uint32_t *__restrict__ act_all)
+{
+    constexpr int MODE = 2;
+    constexpr int NREC = NREC_PLANE;
+    static_assert(FZ_CAP == 64 * Q, "wave 0 takes FZ_CAP active queries in Q rounds of 64");
+    const int L = blockIdx.y * gridDim.x + blockIdx.x; // placement as k_nn_red
+    const int kk = L >> 3;
+    const int b = kk % (int)gridDim.y;
+    const int bx = (L & 7) * ((int)gridDim.x >> 3) + kk / (int)gridDim.y;
+    if (bx >= nblocks) return;
+    const IcpState *S = st + b;
+    if (S->done) return;
+    const int fmode = fz[b].mode;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t row = (size_t)b * nblocks + bx;
+    double *dst = partials + row * REC_STRIDE;
+    __shared__ sf::WaveNN nn_ws[BLK / 64];
+    LanePair P[Q];
+    if (fmode == 2) {
+        // the scan's active queries, FZ_CAP per workgroup from the scan's list (k_reduce_solve_fz wrote it, in row and slot
+        // order), taken by wave 0 in Q rounds; workgroups beyond the list leave at once, k_reduce_solve_fz adds only the rows
+        // that were written.  (Measured: four waves side by side with 64 each, and a fixed grid of resident workgroups
+        // walking the rows with the per-scan state in LDS, are both slower -- 33.8 / 32.1 against 31.3 us per launch, and
+        // the freeze launch 409 against 326 us as a fixed grid.  What a frozen launch costs is the latency of ONE search:
+        // the few queries whose neighbour and runner-up are closer together than the certificate's rounding margins search in
+        // every launch.)
+        if (wv != 0) return;
+        const int64_t total = fz[b].n_active, first = (int64_t)bx * FZ_CAP;
+        if (first >= total) return;
+        const uint32_t cnt = (uint32_t)min<int64_t>(total - first, FZ_CAP);
+        const uint32_t *list = act_all + (size_t)b * nblocks * FZ_CAP + (size_t)first;
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+            const uint32_t i = (uint32_t)(u * 64 + lane);
+            const int slot = i < cnt ? (int)list[i] : n; // n: no query
+            P[u] = nn_pair<MODE, false, false>(g, w, X0x, X0y, X0z, n, b, S, thr, 0.0f, 0.0f, nullptr, qcache, cache_n, slot, n, &nn_ws[0], stats);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = 0.0;
+#pragma unroll
+            for (int u = 0; u < Q; ++u) {
+                const PairTerms t = pair_terms<MODE>(P[u]);
+                add_half<MODE>(t, h, v);
+            }
+            const double t0 = wave_reduce_16(v);
+            if ((lane & 3) == 0 && 16 * h + (lane >> 2) < NREC) dst[16 * h + (lane >> 2)] = t0;
+        }
+        return;
+    }
+    __shared__ double stage[BLK / 64][32];
+    __shared__ uint32_t act_w[BLK / 64][Q];
+    bool active[Q];
+#pragma unroll
+    for (int u = 0; u < Q; ++u) active[u] = false;
+    bool fast = false;
+    const float m_now = (float)S->motion;
+    const float guard = fz[b].guard;
+    const bool attempted = qcache != nullptr && S->cache_live != 0;
+    if (attempted) {
+        bool any_need = false;
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+            const int slot = bx * (BLK * Q) + u * BLK + (int)threadIdx.x;
+            const QueryIn q = query_in<MODE, false>(X0x, X0y, X0z, n, b, S, 0.0f, 0.0f, nullptr, qcache, cache_n, true, slot, n);
+            sf::NNHit hit, seed;
+            float4 tn;
+            any_need = reuse_certificate(q.valid, q.qx, q.qy, q.qz, thr, m_now, q.e, q.c1, q.c2, hit, tn, seed) || any_need;
+            P[u] = make_pair(q, hit, tn);
+            if (fmode == 1) active[u] = !stays_frozen(q, thr, m_now, guard);
+        }
+        fast = __ballot(any_need) == 0ull;
+    }
+    if (!fast) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+            const int slot = bx * (BLK * Q) + u * BLK + (int)threadIdx.x;
+            P[u] = nn_pair<MODE, false, false>(g, w, X0x, X0y, X0z, n, b, S, thr, 0.0f, 0.0f, nullptr, qcache, cache_n, slot, n, &nn_ws[wv], stats);
+            // (freeze launch: the classes stand as taken above -- a lane that searches here failed the plain certificate, so it
+            // failed the guarded one and is active; the others' pairs are the ones the attempt found)
+            if (fmode == 1 && !attempted) active[u] = slot < n;
+        }
+    }
+    if (fmode == 1) {
+        // the row's active list, in slot order (fixed: it is the summation order of the frozen launches)
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+            const unsigned long long bal = __ballot(active[u]);
+            if (lane == 0) act_w[wv][u] = (uint32_t)__popcll(bal);
+        }
+        __syncthreads();
+        uint32_t total = 0;
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+            uint32_t base = 0;
+#pragma unroll
+            for (int ww = 0; ww < BLK / 64; ++ww) {
+                if (ww < wv) base += act_w[ww][u];
+                total += act_w[ww][u];
+            }
+            uint32_t before = 0;
+#pragma unroll
+            for (int uu = 0; uu < Q; ++uu)
+                if (uu < u)
+#pragma unroll
+                    for (int ww = 0; ww < BLK / 64; ++ww) before += act_w[ww][uu];
+            const unsigned long long bal = __ballot(active[u]);
+            const uint32_t rank = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            const uint32_t pos = before + base + rank;
+            if (active[u] && pos < (uint32_t)FZ_CAP) act_ids[row * FZ_CAP + pos] = (uint16_t)(u * BLK + (int)threadIdx.x);
+        }
+        if (threadIdx.x == 0) act_cnt[row] = total; // beyond FZ_CAP: the freeze does not hold (k_reduce_solve_fz)
+    }
+    // the ordinary record: every pair (mode 0) / the active pairs (freeze launch)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 0.0;
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+            LanePair A = P[u];
+            if (fmode == 1) A.ok = A.ok && active[u];
+            const PairTerms t = pair_terms<MODE>(A);
+            add_half<MODE>(t, h, v);
+        }
+        const double t0 = wave_reduce_16(v);
+        if ((lane & 3) == 0) stage[wv][16 * h + (lane >> 2)] = t0;
+    }
+    __syncthreads();
+    if (threadIdx.x < NREC) {
+        const int c = threadIdx.x;
+        dst[c] = ((stage[0][c] + stage[1][c]) + stage[2][c]) + stage[3][c];
+    }
+    if (fmode != 1) return;
+    // the moments of the frozen pairs, 16 at a time through the same wave reduction
+    __shared__ double mstage[BLK / 64][FZ_NMOM];
+#define SF_FZ_CHUNK(H)                                                     \
+    {                                                                      \
+        double v[16];                                                      \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) v[k] = 0.0;         \
+        _Pragma("unroll") for (int u = 0; u < Q; ++u)                      \
+        {                                                                  \
+            const MomIn t = mom_in(P[u], !active[u]);                      \
+            mom_add16<H>(t, v);                                            \
+        }                                                                  \
+        const double t0 = wave_reduce_16(v);                               \
+        if ((lane & 3) == 0) mstage[wv][16 * H + (lane >> 2)] = t0;        \
+    }
+    SF_FZ_CHUNK(0) SF_FZ_CHUNK(1) SF_FZ_CHUNK(2) SF_FZ_CHUNK(3) SF_FZ_CHUNK(4) SF_FZ_CHUNK(5)
+#undef SF_FZ_CHUNK
+    __syncthreads();
+    if (threadIdx.x < FZ_NMOM) {
+        const int c = threadIdx.x;
+        mom_part[row * FZ_NMOM + c] = ((mstage[0][c] + mstage[1][c]) + mstage[2][c]) + mstage[3][c];
+    }
+}
+
+// fixed-order column sums of a slab with rows of STRIDE doubles, NCOL columns (NCOL <= 96), by 1024 threads:
+// thread (slice s of 8, column c of up to 128) adds rows s, s + 8, ...; the 8 slices are then added in order
+template <int STRIDE, int NCOL>
+__device__ __forceinline__ void reduce_columns(const double *__restrict__ part, int nrows, double *out)
+{
+    __shared__ double sl[8][128];
+    const int c = threadIdx.x & 127, sidx = threadIdx.x >> 7;
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    if (c < NCOL) {
+        int r = sidx;
+        for (; r + 24 < nrows; r += 32) {
+            const double a0 = part[(size_t)r * STRIDE + c], a1 = part[(size_t)(r + 8) * STRIDE + c];
+            const double a2 = part[(size_t)(r + 16) * STRIDE + c], a3 = part[(size_t)(r + 24) * STRIDE + c];
+            v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+        }
+        for (; r < nrows; r += 8) v0 += part[(size_t)r * STRIDE + c];
+    }
+    sl[sidx][c] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (threadIdx.x < NCOL) {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += sl[k][threadIdx.x];
+        out[threadIdx.x] = v;
+    }
+    __syncthreads();
+}
+
+// the P2PLANE record (30 sums) of the frozen pairs at the pose D = (R, t) relative to the freeze pose, from their moments;
+// threads 0..63 of the workgroup work, the result is ADDED to rec[] by thread 0 (after a barrier)
+__device__ __forceinline__ void frozen_record(const double *__restrict__ mom, const double *D, double *rec)
+{
+    __shared__ double YY[6][6]; // [k6(c,f)][k6(b,e)] = sum n_c n_f y_b y_e
+    __shared__ double YN[6][3]; // sum n_c n_f y_b
+    __shared__ double CY[3][3]; // sum c n_a y_b
+    __shared__ double SD;       // sum |y - p|^2
+    const int tid = threadIdx.x;
+    auto R = [&](int r, int c) { return D[4 * r + c]; };
+    auto T = [&](int r) { return D[4 * r + 3]; };
+    if (tid < 36) {
+        const int cf = tid / 6, be = tid % 6, bb = k6a(be), ee = k6b(be);
+        double v = 0.0;
+        for (int d = 0; d < 3; ++d)
+            for (int e = 0; e < 3; ++e) v += R(bb, d) * R(ee, e) * mom[6 * cf + k6(d, e)];
+        for (int d = 0; d < 3; ++d) v += (R(bb, d) * T(ee) + T(bb) * R(ee, d)) * mom[36 + 3 * cf + d];
+        v += T(bb) * T(ee) * mom[54 + cf];
+        YY[cf][be] = v;
+    } else if (tid < 54) {
+        const int cf = (tid - 36) / 3, bb = (tid - 36) % 3;
+        double v = T(bb) * mom[54 + cf];
+        for (int d = 0; d < 3; ++d) v += R(bb, d) * mom[36 + 3 * cf + d];
+        YN[cf][bb] = v;
+    } else if (tid < 63) {
+        const int a = (tid - 54) / 3, bb = (tid - 54) % 3;
+        double v = T(bb) * mom[69 + a];
+        for (int d = 0; d < 3; ++d) v += R(bb, d) * mom[60 + 3 * a + d];
+        CY[a][bb] = v;
+    } else if (tid == 63) {
+        double yy = 0.0, yp = 0.0;
+        for (int bb = 0; bb < 3; ++bb) {
+            double q2 = 0.0, l = 0.0, pp = T(bb) * mom[92 + bb];
+            for (int d = 0; d < 3; ++d) {
+                for (int e = 0; e < 3; ++e) q2 += R(bb, d) * R(bb, e) * mom[74 + k6(d, e)];
+                l += R(bb, d) * mom[80 + d];
+                pp += R(bb, d) * mom[83 + 3 * bb + d];
+            }
+            yy += q2 + 2.0 * T(bb) * l + mom[73] * T(bb) * T(bb);
+            yp += pp;
+        }
+        SD = yy - 2.0 * yp + mom[95];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // (y x n)_a = y_b n_c - y_c n_b with (a, b, c) cyclic
+        auto yy = [&](int c, int f, int bb, int ee) { return YY[k6(c, f)][k6(bb, ee)]; };
+        double A[6][6], rhs[6];
+        for (int a = 0; a < 3; ++a) {
+            const int b1 = (a + 1) % 3, c1 = (a + 2) % 3;
+            for (int a2 = a; a2 < 3; ++a2) {
+                const int b2 = (a2 + 1) % 3, c2 = (a2 + 2) % 3;
+                // (y_b1 n_c1 - y_c1 n_b1)(y_b2 n_c2 - y_c2 n_b2)
+                A[a][a2] = yy(c1, c2, b1, b2) - yy(c1, b2, b1, c2) - yy(b1, c2, c1, b2) + yy(b1, b2, c1, c2);
+            }
+            for (int f = 0; f < 3; ++f) A[a][3 + f] = YN[k6(c1, f)][b1] - YN[k6(b1, f)][c1];
+            double s1 = 0.0, s2 = 0.0; // sum_e n_c1 n_e y_b1 y_e, sum_e n_b1 n_e y_c1 y_e
+            for (int e = 0; e < 3; ++e) { s1 += yy(c1, e, b1, e); s2 += yy(b1, e, c1, e); }
+            rhs[a] = (s1 - CY[c1][b1]) - (s2 - CY[b1][c1]);
+        }
+        for (int c = 0; c < 3; ++c) {
+            for (int f = c; f < 3; ++f) A[3 + c][3 + f] = mom[54 + k6(c, f)];
+            double s1 = 0.0;
+            for (int e = 0; e < 3; ++e) s1 += YN[k6(c, e)][e];
+            rhs[3 + c] = s1 - mom[69 + c];
+        }
+        double r2 = mom[72];
+        for (int c = 0; c < 3; ++c) {
+            for (int f = 0; f < 3; ++f) r2 += yy(c, f, c, f);
+            r2 -= 2.0 * CY[c][c];
+        }
+        rec[0] += mom[73];
+        rec[1] += r2;
+        int k = 2;
+        for (int a = 0; a < 6; ++a)
+            for (int c = a; c < 6; ++c) rec[k++] += A[a][c];
+        for (int a = 0; a < 6; ++a) rec[23 + a] += rhs[a];
+        rec[29] += SD;
+    }
+    __syncthreads();
+}
+
+// k_reduce_solve<2> for the launches that may freeze (see k_nn_red_fz); `request`: this solve may ask for a freeze launch
+__global__ __launch_bounds__(RBLK) void k_reduce_solve_fz(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, int n_src, int K,
+                                                          const ScanBox *__restrict__ boxp, FreezeState *__restrict__ fz, const double *__restrict__ mom_part,
+                                                          const uint32_t *__restrict__ act_cnt, const uint16_t *__restrict__ act_ids, uint32_t *__restrict__ act_all,
+                                                          FreezeParams fp, int request)
+{
+    const int b = blockIdx.x;
+    IcpState *S = st + b;
+    if (S->done) return;
+    FreezeState *F = fz + b;
+    const int fmode = F->mode;
+    __shared__ double rec[REC_STRIDE];
+    __shared__ double mom[FZ_NMOM];
+    __shared__ double D[12];
+    __shared__ unsigned long long act_total;
+    __shared__ uint32_t act_worst;
+    // frozen: only the first rows were written, by the workgroups that had a piece of the scan's active list
+    const int rows_live = fmode == 2 ? (int)((F->n_active + FZ_CAP - 1) / FZ_CAP) : nblocks;
+    reduce_partials<NREC_PLANE>(partials + (size_t)b * nblocks * REC_STRIDE, rows_live, rec);
+    if (fmode == 1) {
+        reduce_columns<FZ_NMOM, FZ_NMOM>(mom_part + (size_t)b * nblocks * FZ_NMOM, nblocks, mom);
+        // the rows' active lists -> one list per scan (row order, slot order inside a row): where each row's piece starts ...
+        __shared__ uint32_t pre[RBLK];
+        if (threadIdx.x == 0) { act_total = 0ull; act_worst = 0u; }
+        __syncthreads();
+        uint32_t run = 0;
+        for (int r0 = 0; r0 < nblocks; r0 += RBLK) {
+            const int r = r0 + (int)threadIdx.x;
+            const uint32_t c = r < nblocks ? act_cnt[(size_t)b * nblocks + r] : 0u;
+            pre[threadIdx.x] = c;
+            __syncthreads();
+            for (int off = 1; off < RBLK; off <<= 1) { // inclusive scan of the chunk
+                const uint32_t t = (int)threadIdx.x >= off ? pre[threadIdx.x - off] : 0u;
+                __syncthreads();
+                pre[threadIdx.x] += t;
+                __syncthreads();
+            }
+            const uint32_t start = run + pre[threadIdx.x] - c;
+            if (c > (uint32_t)FZ_CAP) atomicMax(&act_worst, c);
+            if (r < nblocks && c <= (uint32_t)FZ_CAP) // ... and the copy (a row that overflowed: the freeze does not hold, the list is not used)
+                for (uint32_t i = 0; i < c; ++i) act_all[(size_t)b * nblocks * FZ_CAP + start + i] = (uint32_t)r * (uint32_t)(BLK * SF_WIDE_QPL) + act_ids[((size_t)b * nblocks + r) * FZ_CAP + i];
+            run += pre[RBLK - 1];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) act_total = (unsigned long long)run;
+        __syncthreads();
+    } else if (fmode == 2) {
+        if (threadIdx.x < FZ_NMOM) mom[threadIdx.x] = F->mom[threadIdx.x];
+    }
+    if (fmode != 0) {
+        if (threadIdx.x == 0) {
+            if (fmode == 1) { // the freeze pose is this launch's pose: D = identity
+                for (int i = 0; i < 12; ++i) D[i] = (i % 5 == 0) ? 1.0 : 0.0;
+            } else { // D = T_now * Tf^-1 (Tf rigid: inverse = (R^T, -R^T t))
+                const double *Tf = F->Tf;
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c) D[4 * r + c] = S->T[4 * r] * Tf[4 * c] + S->T[4 * r + 1] * Tf[4 * c + 1] + S->T[4 * r + 2] * Tf[4 * c + 2]; // R_now R_f^T
+                    D[4 * r + 3] = 0.0;
+                }
+                for (int r = 0; r < 3; ++r) D[4 * r + 3] = S->T[4 * r + 3] - (D[4 * r] * Tf[3] + D[4 * r + 1] * Tf[7] + D[4 * r + 2] * Tf[11]);
+            }
+        }
+        __syncthreads();
+        frozen_record(mom, D, rec);
+    }
+    if (threadIdx.x == 0) {
+        for (int c = 0; c < NREC_PLANE; ++c) S->rec[c] = rec[c];
+        double To[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) To[i] = S->T[i];
+        const double m0 = S->motion;
+        solve_plane(S, rec, n_src, K);
+        track_motion(S, To, boxp[b]);
+        const double m1 = S->motion, dm = m1 - m0;
+        if (fmode == 1) {
+            F->n_active = (int64_t)act_total;
+            if (act_worst > (uint32_t)FZ_CAP) { // a row could not list its active queries: this launch was an ordinary one in two parts, nothing is frozen
+                F->mode = 0;
+                F->tries += 1;
+            } else {
+                F->mode = 2;
+                F->froze += 1;
+                F->motion0 = m0;
+                for (int i = 0; i < 12; ++i) F->Tf[i] = To[i];
+                for (int i = 0; i < FZ_NMOM; ++i) F->mom[i] = mom[i];
+            }
+        }
+        if (F->mode == 2 && !(m1 - F->motion0 <= (double)F->guard * 0.98)) { // the next launch's pose is beyond what the frozen queries were cleared for
+            F->mode = 0;
+            F->tries += 1;
+            F->thawed += 1;
+        }
+        if (F->mode == 0 && fmode == 0 && request && !S->done && F->tries < fp.max_tries) {
+            // a guard of a few times the last update's motion (ICP steps shrink geometrically); while that is still large the
+            // active lists would be long (or overflow: a freeze launch for nothing) -- wait for a later launch
+            const float gd = fmaxf((float)dm * fp.guard_scale, fp.guard_min);
+            if (gd <= fp.guard_max) { F->guard = gd; F->mode = 1; }
+        }
+    }
+}
+
+__global__ void k_fz_init(FreezeState *__restrict__ fz, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    FreezeState *F = fz + b;
+    F->mode = 0; F->tries = 0; F->froze = 0; F->thawed = 0; F->n_active = 0; F->guard = 0.0f; F->pad = 0.0f; F->motion0 = 0.0;
 }
 
 // multi-GPU split: reduce into the exchange buffer, all-reduce outside, then solve
@@ -1971,6 +2469,11 @@ struct sf_icp {
     std::vector<int> ev_kind;       // SF_PROF_* of every event pair
     std::vector<float> prof_phase[SF_PROF_KINDS]; // sharded path: durations of the other phases, in order
     sf::DevBuf nn_stats;            // per profiled k_nn_red launch: {queries that searched, waves that searched}
+    // frozen pairs (k_nn_red_fz)
+    bool freeze = true;             // sf_icp_set_freeze
+    FreezeParams fz_prm{8.0f, 2.0e-5f, 3.0e-4f, 3};
+    int fz_from = 5;                // launch index of the first launch that may be a freeze launch
+    sf::DevBuf fz_state, fz_part, fz_cnt, fz_ids, fz_all;
     int64_t nn_stats_used = 0;
     static constexpr int64_t NN_STATS_CAP = 1024;
 };
@@ -2036,13 +2539,20 @@ int run_order_sort(sf_icp *icp, int nseg, int64_t longest, int64_t total, const 
     uint16_t *keys = icp->qkeys.as<uint16_t>();
     uint32_t *counts = icp->qkeys2.as<uint32_t>(), *ordered = icp->qidx.as<uint32_t>();
     hipStream_t s = icp->ctx->stream;
-    const dim3 grid((unsigned)src.tiles, (unsigned)nseg), blk(sf::ORD_BLK);
+    src.nseg = nseg;
+    const dim3 grid(sf::order_grid(src.tiles, nseg)), blk(sf::ORD_BLK);
     hipLaunchKernelGGL(k_order_hist, grid, blk, 0, s, src, kf, keys, counts);
     hipLaunchKernelGGL(sf::k_order_scan, dim3((unsigned)nseg), dim3(sf::ORD_BINS), 0, s, counts, src.tiles);
     hipLaunchKernelGGL(k_order_scatter, grid, blk, 0, s, src, keys, counts, ordered);
     const int64_t qplane = seg_off ? total : icp->plane; // sharded: the compact arrays have their own length
-    hipLaunchKernelGGL(k_order_gather, dim3(nblk(total, 256 * GATHER_PER_LANE)), dim3(256), 0, s, icp->X0r.as<float4>(), ordered, total, soa(icp->Xq, qplane, 0),
-                       soa(icp->Xq, qplane, 1), soa(icp->Xq, qplane, 2));
+    if (seg_off) {
+        hipLaunchKernelGGL(k_order_gather, dim3(nblk(total, GATHER_TILE)), dim3(256), 0, s, icp->X0r.as<float4>(), ordered, total, 0, 0, 0, soa(icp->Xq, qplane, 0),
+                           soa(icp->Xq, qplane, 1), soa(icp->Xq, qplane, 2));
+    } else {
+        const int gt = (int)std::max<int64_t>(1, sf::div_up(icp->n, GATHER_TILE));
+        hipLaunchKernelGGL(k_order_gather, dim3(sf::order_grid(gt, nseg)), dim3(256), 0, s, icp->X0r.as<float4>(), ordered, total, (int)icp->n, gt, nseg,
+                           soa(icp->Xq, qplane, 0), soa(icp->Xq, qplane, 1), soa(icp->Xq, qplane, 2));
+    }
     SF_HIP(hipGetLastError());
     return SF_OK;
 }
@@ -2155,13 +2665,13 @@ void prof_collect(sf_icp *icp)
 sf_icp::GraphKey graph_key_now(const sf_icp *icp, int mode)
 {
     sf_icp::GraphKey k;
-    k.mode = mode; k.iters = icp->prm.num_iters; k.batch = icp->batch; k.window = icp->map->window.kind; k.ordered = (int)icp->ordered; k.reuse = (int)icp->reuse;
+    k.mode = mode; k.iters = icp->prm.num_iters; k.batch = icp->batch; k.window = icp->map->window.kind; k.ordered = (int)icp->ordered; k.reuse = (int)icp->reuse | (icp->freeze ? 2 : 0) | (icp->fz_from << 2);
     k.n = (mode == SF_ICP_REF_CPP && icp->batch == 1) ? -icp->n_cap : icp->n; // REF_CPP, one scan: any count of the same capacity replays
     k.map = (const void *)icp->map;
     k.map_generation = icp->map->generation;
-    k.max_corr = icp->prm.max_corr; k.accept = icp->prm.accept; k.eps = icp->prm.eps;
+    k.max_corr = icp->prm.max_corr; k.accept = icp->prm.accept; k.eps = icp->prm.eps + icp->fz_prm.guard_scale * 1.0e-3f + icp->fz_prm.guard_min + icp->fz_prm.guard_max + (float)icp->fz_prm.max_tries; // (the freeze parameters travel by value too)
     const sf::DevBuf *bufs[] = {&icp->X0, &icp->X0r, &icp->X, &icp->Xq, &icp->qcache, &icp->corr, &icp->state, &icp->partials, &icp->d_box, &icp->d_boxes, &icp->n_dev,
-                                &icp->map->pts4, &icp->map->nrm4, &icp->map->cell_start, &icp->map->d_window};
+                                &icp->map->pts4, &icp->map->nrm4, &icp->map->cell_start, &icp->map->d_window, &icp->fz_state, &icp->fz_part, &icp->fz_cnt, &icp->fz_ids, &icp->fz_all};
     k.epochs = (uint64_t)icp->plane;
     for (const sf::DevBuf *b : bufs) k.epochs = k.epochs * 1000003ull + b->epoch;
     return k;
@@ -2198,6 +2708,37 @@ void launch_nn_red(sf_icp *icp, bool sharded = false)
     else SF_LAUNCH_NNRED(false, false);
 #undef SF_LAUNCH_NNRED_Q
 #undef SF_LAUNCH_NNRED
+}
+
+// frozen pairs: P2PLANE launch list of wide scans with the neighbour reuse on, whole map, unsharded
+bool freeze_on(const sf_icp *icp, int mode)
+{
+    return mode == SF_ICP_P2PLANE && icp->freeze && icp->reuse && icp->qpl == SF_WIDE_QPL && icp->map->window.kind == 0 && !icp->shard &&
+           icp->prm.num_iters > icp->fz_from + 1 && icp->fz_from >= VERIFY_FROM_SEARCH;
+}
+
+int freeze_alloc(sf_icp *icp)
+{
+    const size_t rows = (size_t)icp->batch * (size_t)icp->nblocks_nn;
+    SF_TRY(icp->fz_state.reserve(sizeof(FreezeState) * (size_t)icp->batch));
+    SF_TRY(icp->fz_part.reserve(sizeof(double) * FZ_NMOM * rows));
+    SF_TRY(icp->fz_cnt.reserve(sizeof(uint32_t) * rows));
+    SF_TRY(icp->fz_ids.reserve(sizeof(uint16_t) * FZ_CAP * rows));
+    SF_TRY(icp->fz_all.reserve(sizeof(uint32_t) * FZ_CAP * rows));
+    return SF_OK;
+}
+
+void launch_nn_red_fz(sf_icp *icp)
+{
+    sf_map *m = icp->map;
+    const int nb = icp->nblocks_nn;
+    const dim3 grid((unsigned)((nb + 7) & ~7), (unsigned)icp->batch), blk(BLK);
+    ProfScope ps(icp);
+    uint32_t *stats = nullptr;
+    if (icp->profiling && icp->nn_stats.p && icp->nn_stats_used < sf_icp::NN_STATS_CAP) stats = icp->nn_stats.as<uint32_t>() + 2 * NN_STATS_SHARDS * icp->nn_stats_used++;
+    hipLaunchKernelGGL((k_nn_red_fz<SF_WIDE_QPL>), grid, blk, 0, icp->ctx->stream, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n,
+                       icp->state.as<IcpState>(), o3d_thr(icp), icp->partials.as<double>(), nb, icp->qcache.as<float4>(), icp->cache_n, stats,
+                       icp->fz_state.as<FreezeState>(), icp->fz_part.as<double>(), icp->fz_cnt.as<uint32_t>(), icp->fz_ids.as<uint16_t>(), icp->fz_all.as<uint32_t>());
 }
 
 // A hipMemcpyAsync from pageable memory makes the host wait until the stream has reached it -- that would turn every
@@ -2250,9 +2791,18 @@ int enqueue_align(sf_icp *icp, int mode)
             hipLaunchKernelGGL(k_reduce_solve<1>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K, icp->d_boxes.as<ScanBox>());
         }
     } else if (mode == SF_ICP_P2PLANE) {
+        const bool fz = freeze_on(icp, mode);
+        if (fz) { // (buffers: freeze_alloc, before any capture)
+            hipLaunchKernelGGL(k_fz_init, dim3(nblk(B, 64)), dim3(64), 0, s, icp->fz_state.as<FreezeState>(), B);
+        }
         for (int k = 0; k < K; ++k) {
-            launch_nn_red<2>(icp);
-            hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K, icp->d_boxes.as<ScanBox>());
+            if (fz && k >= icp->fz_from) launch_nn_red_fz(icp);
+            else launch_nn_red<2>(icp);
+            if (fz && k + 1 >= icp->fz_from)
+                hipLaunchKernelGGL(k_reduce_solve_fz, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, K, icp->d_boxes.as<ScanBox>(), icp->fz_state.as<FreezeState>(),
+                                   icp->fz_part.as<double>(), icp->fz_cnt.as<uint32_t>(), icp->fz_ids.as<uint16_t>(), icp->fz_all.as<uint32_t>(), icp->fz_prm, (int)(k + 2 < K));
+            else
+                hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K, icp->d_boxes.as<ScanBox>());
         }
     } else {
         SF_TRY(icp->X.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(icp->plane, 1)));
@@ -2666,6 +3216,41 @@ extern "C" int sf_icp_set_nn_reuse(sf_icp *icp, int on)
     return SF_OK;
 }
 
+extern "C" int sf_icp_set_freeze(sf_icp *icp, int on)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    icp->freeze = on != 0;
+    return SF_OK;
+}
+
+extern "C" int sf_icp_set_freeze_params(sf_icp *icp, float guard_scale, float guard_min, float guard_max, int max_tries, int from_launch)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    SF_CHECK(guard_scale >= 0.0f && guard_min >= 0.0f && guard_max >= guard_min && max_tries >= 0 && from_launch >= VERIFY_FROM_SEARCH && from_launch < 1024, SF_ERR_INVALID,
+             "bad freeze parameters");
+    icp->fz_prm = FreezeParams{guard_scale, guard_min, guard_max, max_tries};
+    icp->fz_from = from_launch;
+    return SF_OK;
+}
+
+extern "C" int sf_icp_freeze_stats(sf_icp *icp, int64_t out[5])
+{
+    SF_CHECK(icp && out, SF_ERR_INVALID, "bad arguments");
+    for (int i = 0; i < 5; ++i) out[i] = 0;
+    if (!freeze_on(icp, icp->last_mode) || icp->last_fused || !icp->fz_state.p || icp->batch <= 0) return SF_OK;
+    std::vector<FreezeState> h((size_t)icp->batch);
+    SF_HIP(hipMemcpyAsync(h.data(), icp->fz_state.p, sizeof(FreezeState) * h.size(), hipMemcpyDeviceToHost, icp->ctx->stream));
+    SF_HIP(hipStreamSynchronize(icp->ctx->stream));
+    for (const FreezeState &f : h) {
+        out[0] += f.froze;             // freeze launches that held
+        out[1] += f.thawed;            // scans that moved beyond their guard afterwards
+        out[2] += f.tries - f.thawed;  // freeze launches that did not hold (a row's active list overflowed)
+        out[3] += f.n_active;          // active queries of the last freeze launch
+        out[4] += f.mode == 2 ? 1 : 0; // scans frozen when the alignment ended
+    }
+    return SF_OK;
+}
+
 extern "C" int sf_icp_graph_counts(sf_icp *icp, int64_t *captures, int64_t *launches)
 {
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
@@ -2734,6 +3319,7 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     }
     SF_TRY(order_queries(icp, mode)); // plain launches ahead of the (replayed) iteration graph
     if (mode != SF_ICP_REF_CPP) SF_TRY(reuse_reset(icp, icp->n * icp->batch));
+    if (freeze_on(icp, mode)) SF_TRY(freeze_alloc(icp));
     // O3D_P2P / P2PLANE take the window by value (it moves with the pose: plain launches then); REF_CPP reads it from device memory
     if (icp->use_graph && !icp->profiling && (icp->map->window.kind == 0 || mode == SF_ICP_REF_CPP)) {
         if (mode == SF_ICP_REF_CPP) { // buffers must exist before capture (and before the key is formed)

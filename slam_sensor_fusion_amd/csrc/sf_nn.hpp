@@ -421,6 +421,19 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
             valid = false;
         }
     }
+    if (valid) {
+        // a query farther from the map's bounding box (the grid's: every point is inside it) than the acceptance radius has
+        // no neighbour -- known without a walk through empty rings, and the distance to the box is its runner-up bound: scan
+        // points beyond the rim of the map certify as "still nothing" from then on instead of searching in every launch
+        const float ox = fmaxf(fmaxf(g.org[0] - qx, qx - (g.org[0] + (float)nx * g.h)), 0.0f);
+        const float oy = fmaxf(fmaxf(g.org[1] - qy, qy - (g.org[1] + (float)ny * g.h)), 0.0f);
+        const float oz = fmaxf(fmaxf(g.org[2] - qz, qz - (g.org[2] + (float)nz * g.h)), 0.0f);
+        const float gap = fmaxf(sqrtf(ox * ox + oy * oy + oz * oz) * 0.9995f - 1.0e-3f, 0.0f); // (1 mm: the float32 corner of the box)
+        if (gap * gap > thr) {
+            hit.lb2 = gap * gap;
+            valid = false;
+        }
+    }
     if (valid && seed.j >= 0 && seed.d2 < thr) { hit.d2 = seed.d2; hit.j = seed.j; hit.px = seed.px; hit.py = seed.py; hit.pz = seed.pz; }
     uint32_t mask = 0;
     if (valid) {

@@ -39,8 +39,24 @@ struct OrderSrc {
     const uint32_t *src_idx;     // element e of the segment space -> global query id, or nullptr (identity)
     const uint32_t *seg_off;     // segment offsets [nseg + 1], or nullptr (uniform: segment b = [b * n, (b + 1) * n))
     int n;                       // uniform segment length
-    int tiles;                   // tiles per segment (grid.x)
+    int tiles;                   // tiles per segment
+    int nseg;                    // segments (grid: order_grid(tiles, nseg), see order_block)
 };
+
+// XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in launch order (linear id L runs on XCD L % 8).
+// A one-dimensional grid of tiles x (segments rounded up to 8): all tiles of segment b run on XCD b % 8, eight segments
+// at a time, so what a segment's workgroups write at random inside the segment (the ordered ids: 4-byte stores into
+// 0.8 MB per 200 k-point scan) is merged into whole lines in ONE L2 and what they read at random (k_order_gather: 16-byte
+// records, 3.2 MB per scan) is fetched into one L2 once -- a (tiles, segments) grid spreads every segment over the
+// eight L2s, which do not share lines.  -> false: no such segment (padding)
+__device__ __forceinline__ bool order_block(int tiles, int nseg, int *b, int *tile)
+{
+    const int lin = blockIdx.x, xcd = lin & 7, k = lin >> 3;
+    *tile = k % tiles;
+    *b = (k / tiles) * 8 + xcd;
+    return *b < nseg;
+}
+inline unsigned order_grid(int tiles, int nseg) { return (unsigned)tiles * (unsigned)((nseg + 7) & ~7); }
 
 __device__ __forceinline__ void order_segment(const OrderSrc &s, int b, uint32_t *start, uint32_t *len)
 {
@@ -73,7 +89,8 @@ template <class KEYFN>
 __device__ __forceinline__ void order_hist_body(const OrderSrc &s, KEYFN keyfn, uint16_t *__restrict__ keys, uint32_t *__restrict__ counts)
 {
     __shared__ uint32_t h[ORD_BINS];
-    const int b = blockIdx.y, tile = blockIdx.x;
+    int b, tile;
+    if (!order_block(s.tiles, s.nseg, &b, &tile)) return;
     uint32_t seg_start, seg_len;
     order_segment(s, b, &seg_start, &seg_len);
     uint32_t *dst = counts + ((size_t)b * (s.tiles + 1) + tile) * ORD_BINS; // row `tiles` of a segment's table: the bucket starts (k_order_scan)
@@ -140,7 +157,8 @@ __global__ __launch_bounds__(ORD_BINS) void k_order_scan(uint32_t *__restrict__ 
 __device__ __forceinline__ void order_scatter_body(const OrderSrc &s, const uint16_t *__restrict__ keys, const uint32_t *__restrict__ starts, uint32_t *__restrict__ out)
 {
     __shared__ uint32_t ctr[ORD_WAVES][ORD_BINS];
-    const int b = blockIdx.y, tile = blockIdx.x;
+    int b, tile;
+    if (!order_block(s.tiles, s.nseg, &b, &tile)) return;
     uint32_t seg_start, seg_len;
     order_segment(s, b, &seg_start, &seg_len);
     if ((uint32_t)tile * ORD_TILE >= seg_len) return;

@@ -1,0 +1,129 @@
+"""Frozen pairs (sf_icp_set_freeze, k_nn_red_fz / k_reduce_solve_fz in sf_icp.hip): once a wide scan's pairs are certified to stay
+as they are, the P2PLANE normal equations are evaluated from 96 moments of those pairs -- a polynomial in the pose -- instead
+of a pass over the scan; queries close to a change stay active and are evaluated launch by launch.  No reference
+counterpart (the reference searches every point in every iteration, localization/src/icp_point_to_point.cpp:64-69).
+
+Checked here: the result equals the launch-by-launch evaluation (same pairs: n_corr and iterations equal; float64 sums in
+another order: poses within 1e-11) and the oracle (1e-9, as every P2PLANE parity test); bitwise equal from run to run, under
+graph replay and whatever else is in the batch; and the paths around the happy one -- a guard so small that every scan
+thaws at once, a guard so large that the active lists overflow, an in-between guard with thousands of active queries,
+other first launches -- all give that same result."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_SCAN = 140_000          # above 131 072: two queries per lane, the launch list (never the single-launch kernels)
+
+
+@pytest.fixture(scope="module")
+def world(api, ctx, orc, synth):
+    raw = synth.make_map(400_000)
+    ds = orc.voxel_pcl(raw, 0.1)[0]
+    mp = api.Map(ctx, api.Cloud(ctx, ds), 0.25)
+    mp.estimate_normals(0.25)
+    scans = np.stack([synth.make_scan(ds, N_SCAN, scan_id=40 + k)[0] for k in range(3)])
+    inits = np.stack([np.eye(4), synth.make_T((0.04, -0.03, 0.02), (0.2, -0.1, 0.3)), synth.make_T((-0.05, 0.05, 0.0), (0.0, 0.3, -0.4))])
+    return dict(map=ds, mp=mp, scans=scans, inits=inits)
+
+
+def run(api, ctx, world, freeze, graph=False, params=None, scans=None, inits=None, iters=20):
+    icp = api.Icp(ctx, 0.5, iters, 0.05, 1e-5)
+    icp.set_target(world["mp"])
+    icp.use_graph(graph)
+    icp.set_query_order("cell")      # (auto orders a batch by cell and a single scan not: another summation order)
+    icp.set_freeze(freeze)
+    if params:
+        icp.set_freeze_params(**params)
+    icp.set_source_batch(world["scans"] if scans is None else scans)
+    icp.set_initial_batch(world["inits"] if inits is None else inits)
+    res = icp.align_batch("p2plane")
+    stats = icp.freeze_stats()
+    icp.close()
+    return res, stats
+
+
+def same_result(a, b, tol=1e-11):
+    for x, y in zip(a, b):
+        assert x["iterations"] == y["iterations"] and x["n_corr"] == y["n_corr"] and x["flags"] == y["flags"] and x["converged"] == y["converged"]
+        assert np.abs(x["T64"] - y["T64"]).max() < tol, np.abs(x["T64"] - y["T64"]).max()
+        assert abs(x["rmse"] - y["rmse"]) < 1e-11 and x["fitness"] == y["fitness"]
+
+
+def bitwise(a, b):
+    for x, y in zip(a, b):
+        assert np.array_equal(x["T64"], y["T64"]) and x["rmse"] == y["rmse"] and x["n_corr"] == y["n_corr"]
+
+
+def test_frozen_pairs_equal_the_launch_by_launch_evaluation(api, ctx, synth, world):
+    off, s_off = run(api, ctx, world, False)
+    on, s_on = run(api, ctx, world, True)
+    assert s_off == {"froze": 0, "thawed": 0, "failed": 0, "active_queries": 0, "frozen_at_end": 0}
+    assert s_on["froze"] >= 3 and s_on["frozen_at_end"] == 3 and s_on["failed"] == 0          # every scan froze and stayed frozen
+    assert 0 <= s_on["active_queries"] < 0.05 * 3 * N_SCAN
+    same_result(on, off)
+    for r in on:
+        assert r["iterations"] == 20 and r["fitness"] > 0.99
+    dt, dr = synth.pose_error(on[0]["T64"], synth.t_true())
+    assert dt < 5e-4 and dr < 5e-5
+    again, _ = run(api, ctx, world, True)
+    bitwise(on, again)                                                                        # run to run
+    replay, _ = run(api, ctx, world, True, graph=True)
+    bitwise(on, replay)                                                                       # graph replay == plain launches
+    single, _ = run(api, ctx, world, True, scans=world["scans"][1:2], inits=world["inits"][1:2])
+    bitwise(on[1:2], single)                                                                  # whatever else is in the batch
+
+
+def test_frozen_pairs_against_the_oracle(api, ctx, orc, synth, world):
+    normals, _ = world["mp"].download_normals()
+    on, stats = run(api, ctx, world, True, scans=world["scans"][1:2], inits=world["inits"][1:2])
+    assert stats["frozen_at_end"] == 1
+    o = orc.icp_p2plane(world["scans"][1], world["map"], normals, world["inits"][1], 0.5, 20)
+    assert on[0]["iterations"] == o["iterations"] == 20
+    dt, dr = synth.pose_error(on[0]["T64"], o["T"])
+    assert dt < 1e-9 and dr < 1e-9, (dt, dr)
+
+
+@pytest.mark.parametrize("name,params,expect", [
+    ("thaws_at_once", dict(guard_scale=0.0, guard_min=1e-12, guard_max=1e-12), lambda s: s["thawed"] >= 3 and s["frozen_at_end"] == 0),
+    ("lists_overflow", dict(guard_scale=0.0, guard_min=0.2, guard_max=0.2), lambda s: s["failed"] >= 3 and s["froze"] == 0),
+    ("many_active", dict(guard_scale=0.0, guard_min=1e-3, guard_max=1e-3), lambda s: s["froze"] >= 3 and s["active_queries"] > 2000),
+    ("early", dict(from_launch=4, guard_max=1e-3), lambda s: s["froze"] >= 3),
+    ("late", dict(from_launch=12), lambda s: s["froze"] >= 3 and s["frozen_at_end"] == 3),
+    ("one_try", dict(max_tries=1, guard_scale=0.0, guard_min=1e-12, guard_max=1e-12), lambda s: s["thawed"] == 3),
+])
+def test_paths_around_the_frozen_one_give_the_same_result(api, ctx, world, name, params, expect):
+    off, _ = run(api, ctx, world, False)
+    on, stats = run(api, ctx, world, True, params=params)
+    assert expect(stats), (name, stats)
+    same_result(on, off)
+    replay, s2 = run(api, ctx, world, True, graph=True, params=params)
+    assert s2 == stats
+    bitwise(on, replay)
+
+
+def test_outliers_and_a_scan_leaving_the_acceptance_radius(api, ctx, synth, world):
+    """A third of the scan has no map point within the acceptance radius (rejected pairs, frozen as such), a band sits right
+    at it (active: their status can change), and one scan is empty of finite points."""
+    rng = np.random.default_rng(5)
+    scans = world["scans"].copy()
+    n = scans.shape[1]
+    scans[0, : n // 3] += np.array([0.0, 0.0, 30.0], dtype=np.float32)          # far above the map
+    scans[1, : n // 10, 2] += rng.uniform(0.2, 0.4, n // 10).astype(np.float32)    # around the 0.3 m acceptance radius below
+    scans[2, ::5] = np.nan
+    icp_args = dict(scans=scans, inits=world["inits"])
+
+    def go(freeze):
+        icp = api.Icp(ctx, 0.3, 20, 0.05, 1e-5)
+        icp.set_target(world["mp"])
+        icp.set_freeze(freeze)
+        icp.set_source_batch(icp_args["scans"])
+        icp.set_initial_batch(icp_args["inits"])
+        r = icp.align_batch("p2plane")
+        s = icp.freeze_stats()
+        icp.close()
+        return r, s
+    off, _ = go(False)
+    on, stats = go(True)
+    assert stats["froze"] >= 2
+    same_result(on, off, tol=1e-10)

@@ -585,11 +585,18 @@ def test_nn_reuse_fuzz_wide_scans(api, ctx, synth):
                 icp = api.Icp(ctx, thr, 12, 0.05, 1e-5)
                 icp.set_target(mp)
                 icp.set_nn_reuse(reuse)
+                icp.set_freeze(False)       # bit for bit: the frozen-pair evaluation sums in another order (tests/test_gpu_freeze.py and below)
                 icp.use_graph(graph)
                 icp.set_query_order("cell" if trial % 2 else "as_given")
                 icp.set_source_batch(scans)
                 icp.set_initial_batch(np.stack(inits))
                 res.append(icp.align_batch(mode))
+                if mode == "p2plane" and reuse and not graph:   # frozen pairs on the same adversarial maps: same pairs, sums equal to rounding
+                    icp.set_freeze(True)
+                    fz = icp.align_batch(mode)
+                    for a, b in zip(res[-1], fz):
+                        assert a["n_corr"] == b["n_corr"] and a["iterations"] == b["iterations"] and a["flags"] == b["flags"], (trial, mode)
+                        assert np.allclose(a["T64"], b["T64"], rtol=0, atol=1e-9, equal_nan=True), (trial, np.abs(a["T64"] - b["T64"]).max())
                 icp.close()
             for other in res[1:]:
                 for a, b in zip(res[0], other):
