@@ -195,7 +195,7 @@ def main():
         icp.use_graph(not args.no_graph)
         icp.set_query_order(args.query_order)
         icp.set_nn_reuse(not args.no_nn_reuse)
-        icp.set_freeze(not args.no_freeze)
+        icp.set_freeze(False if args.no_freeze else "auto")
         return icp
 
     # ---------------- the registration driver of this rank
@@ -618,7 +618,7 @@ def main():
                 step()
             torch.cuda.synchronize()
             extras["value_no_freeze"] = B * k / (time.perf_counter() - t1)
-            icp.set_freeze(True)
+            icp.set_freeze("auto")
         # upload-inclusive: every step uploads its batch from pinned host memory.  Double buffering: the raw H2D copy of
         # batch k+1 runs on a copy stream into one of two staging buffers while batch k is registered on the compute
         # stream, which picks the staged batch up on the device (sf_icp_set_source_batch_device) once its copy event has

@@ -285,8 +285,10 @@ int sf_icp_set_nn_reuse(sf_icp *icp, int on);
  * pairs are certified to stay as they are while it moves by a guard distance more, one launch forms the 96 moments of
  * those pairs and the iterations after it evaluate the normal equations from the moments (a polynomial in the pose)
  * instead of streaming the scan; queries too close to a change stay "active" and are evaluated launch by launch.
- * Same pairs, same float64 sums up to summation rounding (~1e-13 of a pose).  Default on; no reference counterpart
- * (the reference searches every point in every iteration, icp_point_to_point.cpp:64-69). */
+ * Same pairs, same float64 sums up to summation rounding (~1e-13 of a pose).  on: 0 never, 1 (default) when the batch holds
+ * at least 4 M queries -- a frozen launch costs the latency of one search whatever the batch, a small batch is faster
+ * without --, 2 always.  No reference counterpart (the reference searches every point in every iteration,
+ * icp_point_to_point.cpp:64-69). */
 int sf_icp_set_freeze(sf_icp *icp, int on);
 /* guard = max(guard_scale x motion of the last pose update, guard_min) [m]; a freeze launch is asked for once that is at most
  * guard_max (a larger guard means long active lists), at most max_tries times per alignment, from launch index

@@ -538,9 +538,11 @@ class Icp:
     def set_nn_reuse(self, on=True):
         _check(self.lib.sf_icp_set_nn_reuse(self.h, C.c_int(int(on))))
 
-    def set_freeze(self, on=True):
-        """Frozen pairs (sf_icp_set_freeze): P2PLANE launch list of wide scans, see include/slamfusion.h."""
-        _check(self.lib.sf_icp_set_freeze(self.h, C.c_int(int(on))))
+    def set_freeze(self, on="auto"):
+        """Frozen pairs (sf_icp_set_freeze): P2PLANE launch list of wide scans, see include/slamfusion.h.
+        False / "off", "auto" (default: batches of at least 4 M queries), True / "always"."""
+        code = {False: 0, "off": 0, "auto": 1, True: 2, "always": 2}[on]
+        _check(self.lib.sf_icp_set_freeze(self.h, C.c_int(code)))
 
     def set_freeze_params(self, guard_scale=8.0, guard_min=2.0e-5, guard_max=3.0e-4, max_tries=3, from_launch=5):
         _check(self.lib.sf_icp_set_freeze_params(self.h, C.c_float(guard_scale), C.c_float(guard_min), C.c_float(guard_max), C.c_int(max_tries), C.c_int(from_launch)))

@@ -1240,6 +1240,7 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve(IcpState *__restrict__ st
 //   [74,80) x_d x_e   [80,83) x_d   [83,92) p_a x_d (83 + 3 a + d)   [92,95) p_a   95 |p|^2
 constexpr int FZ_NMOM = 96;
 constexpr int FZ_CAP = 128;  // active queries one slab row can list (of its 256 * Q)
+constexpr int64_t FREEZE_AUTO_MIN_QUERIES = 4000000; // sf_icp_set_freeze(1): batches from this many queries on
 struct FreezeState {
     int mode;         // 0: every query evaluated launch by launch, 1: the next launch is a freeze launch, 2: frozen
     int tries;        // freeze launches that did not hold (a row's list overflowed) + thaws
@@ -2470,7 +2471,7 @@ struct sf_icp {
     std::vector<float> prof_phase[SF_PROF_KINDS]; // sharded path: durations of the other phases, in order
     sf::DevBuf nn_stats;            // per profiled k_nn_red launch: {queries that searched, waves that searched}
     // frozen pairs (k_nn_red_fz)
-    bool freeze = true;             // sf_icp_set_freeze
+    int freeze = 1;                 // sf_icp_set_freeze: 0 off, 1 when the batch is large enough to gain (FREEZE_AUTO_MIN_QUERIES), 2 always
     FreezeParams fz_prm{8.0f, 2.0e-5f, 3.0e-4f, 3};
     int fz_from = 5;                // launch index of the first launch that may be a freeze launch
     sf::DevBuf fz_state, fz_part, fz_cnt, fz_ids, fz_all;
@@ -2665,7 +2666,7 @@ void prof_collect(sf_icp *icp)
 sf_icp::GraphKey graph_key_now(const sf_icp *icp, int mode)
 {
     sf_icp::GraphKey k;
-    k.mode = mode; k.iters = icp->prm.num_iters; k.batch = icp->batch; k.window = icp->map->window.kind; k.ordered = (int)icp->ordered; k.reuse = (int)icp->reuse | (icp->freeze ? 2 : 0) | (icp->fz_from << 2);
+    k.mode = mode; k.iters = icp->prm.num_iters; k.batch = icp->batch; k.window = icp->map->window.kind; k.ordered = (int)icp->ordered; k.reuse = (int)icp->reuse | (icp->freeze << 1) | (icp->fz_from << 3);
     k.n = (mode == SF_ICP_REF_CPP && icp->batch == 1) ? -icp->n_cap : icp->n; // REF_CPP, one scan: any count of the same capacity replays
     k.map = (const void *)icp->map;
     k.map_generation = icp->map->generation;
@@ -2713,7 +2714,10 @@ void launch_nn_red(sf_icp *icp, bool sharded = false)
 // frozen pairs: P2PLANE launch list of wide scans with the neighbour reuse on, whole map, unsharded
 bool freeze_on(const sf_icp *icp, int mode)
 {
-    return mode == SF_ICP_P2PLANE && icp->freeze && icp->reuse && icp->qpl == SF_WIDE_QPL && icp->map->window.kind == 0 && !icp->shard &&
+    // a frozen launch costs the latency of one search (31 us measured) + the solve, whatever the batch: below ~4 M queries per
+    // launch a verifying launch is cheaper than that (one 200 k-point scan: 0.39 ms per alignment without, 0.48 ms with)
+    const bool wanted = icp->freeze == 2 || (icp->freeze == 1 && icp->n * icp->batch >= FREEZE_AUTO_MIN_QUERIES);
+    return mode == SF_ICP_P2PLANE && wanted && icp->reuse && icp->qpl == SF_WIDE_QPL && icp->map->window.kind == 0 && !icp->shard &&
            icp->prm.num_iters > icp->fz_from + 1 && icp->fz_from >= VERIFY_FROM_SEARCH;
 }
 
@@ -3219,7 +3223,8 @@ extern "C" int sf_icp_set_nn_reuse(sf_icp *icp, int on)
 extern "C" int sf_icp_set_freeze(sf_icp *icp, int on)
 {
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
-    icp->freeze = on != 0;
+    SF_CHECK(on >= 0 && on <= 2, SF_ERR_INVALID, "sf_icp_set_freeze: 0 (off), 1 (auto) or 2 (always)");
+    icp->freeze = on;
     return SF_OK;
 }
 

@@ -32,7 +32,8 @@ def run(api, ctx, world, freeze, graph=False, params=None, scans=None, inits=Non
     icp.set_target(world["mp"])
     icp.use_graph(graph)
     icp.set_query_order("cell")      # (auto orders a batch by cell and a single scan not: another summation order)
-    icp.set_freeze(freeze)
+    if freeze is not None:
+        icp.set_freeze(freeze)       # True = always; the default ("auto") freezes batches of at least 4 M queries only
     if params:
         icp.set_freeze_params(**params)
     icp.set_source_batch(world["scans"] if scans is None else scans)
@@ -68,6 +69,9 @@ def test_frozen_pairs_equal_the_launch_by_launch_evaluation(api, ctx, synth, wor
     assert dt < 5e-4 and dr < 5e-5
     again, _ = run(api, ctx, world, True)
     bitwise(on, again)                                                                        # run to run
+    auto, s_auto = run(api, ctx, world, None)
+    assert s_auto == s_off                                                                    # 0.42 M queries: a frozen launch would cost more than it saves
+    bitwise(auto, off)
     replay, _ = run(api, ctx, world, True, graph=True)
     bitwise(on, replay)                                                                       # graph replay == plain launches
     single, _ = run(api, ctx, world, True, scans=world["scans"][1:2], inits=world["inits"][1:2])

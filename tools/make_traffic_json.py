@@ -17,7 +17,8 @@ reuse = (sys.argv[5] if len(sys.argv) > 5 else "reuse") == "reuse"
 kname = "k_ref_nn" if mode == "ref_cpp" else "k_nn_red"
 rd = json.load(open(prefix + "_rdsz_pmc.json"))
 wr = json.load(open(prefix + "_wrsz_pmc.json"))
-key = max((k for k in rd if k.startswith(kname)), key=lambda k: rd[k]["TCC_EA0_RDREQ_sum"]["avg"])   # the batched launches
+mine = lambda k: k.startswith(kname) and not k.startswith("k_nn_red_fz")   # (k_nn_red_fz: the launches after the freeze, reported apart)
+key = max((k for k in rd if mine(k)), key=lambda k: rd[k]["TCC_EA0_RDREQ_sum"]["avg"])   # the batched launches
 r, w = rd[key], wr[key]
 n32, n64, n128, nall = (r["TCC_EA0_RDREQ_%s" % s]["avg"] for s in ("32B_sum", "64B_sum", "128B_sum", "sum"))
 other = nall - n32 - n64 - n128
@@ -44,12 +45,24 @@ except (OSError, KeyError):
 avg_ns = None
 try:
     tr = json.load(open(prefix + "_final_kernel_trace_by_grid.json"))
-    tk = max((k for k in tr if k.startswith(kname)), key=lambda k: tr[k]["launches"] * tr[k]["avg_ns"])
+    tk = max((k for k in tr if mine(k)), key=lambda k: tr[k]["launches"] * tr[k]["avg_ns"])
     avg_ns = tr[tk]["avg_ns"]
 except (OSError, KeyError, ValueError):
     pass
+fz = None
+try:   # the frozen-pair launches (k_nn_red_fz: one freeze launch + the frozen ones per alignment), averaged over all of them
+    fk = max((k for k in rd if k.startswith("k_nn_red_fz")), key=lambda k: rd[k]["TCC_EA0_RDREQ_sum"]["avg"])
+    fr, fw = rd[fk], wr[fk]
+    f_read = sum(sz * fr["TCC_EA0_RDREQ_%s" % nm]["avg"] for sz, nm in ((32, "32B_sum"), (64, "64B_sum"), (128, "128B_sum")))
+    f_write = 64 * fw["TCC_EA0_WRREQ_64B_sum"]["avg"] + 32 * max(fw["TCC_EA0_WRREQ_sum"]["avg"] - fw["TCC_EA0_WRREQ_64B_sum"]["avg"], 0.0)
+    ft = max((k for k in tr if k.startswith("k_nn_red_fz")), key=lambda k: tr[k]["launches"] * tr[k]["avg_ns"])
+    fz = {"kernel": fk.split(" grid=")[0], "traffic_bytes_per_launch_avg": f_read + f_write, "avg_launch_ns_kernel_trace": tr[ft]["avg_ns"],
+          "min_launch_ns": tr[ft]["min_ns"], "max_launch_ns": tr[ft]["max_ns"], "launches_traced": tr[ft]["launches"]}
+except (ValueError, KeyError, NameError):
+    pass
 out = {
     "kernel": key.split(" grid=")[0],
+    "frozen_pairs_kernel": fz,
     "avg_launch_ns_kernel_trace": avg_ns,
     "frac_of_hbm_peak_kernel_trace": ((read_b + write_b) / (avg_ns * 1e-9) / 8e12) if avg_ns else None,
     "config": {"scan_points": 200000, "map_points": 10000000, "batch": batch, "iters": iters, "mode": mode, "nn_reuse": reuse},
