@@ -1247,7 +1247,7 @@ struct FreezeState {
     int froze, thawed;
     int64_t n_active; // active queries of the last freeze launch
     float guard;      // motion allowed after the freeze [m]
-    float pad;
+    int launch_mode;  // `mode` as the launch in flight found it (the solve's bookkeeping needs it when reduce and solve are two kernels)
     double motion0;   // IcpState::motion the freeze launch classified with
     double Tf[12];    // the pose of the freeze launch
     double mom[FZ_NMOM];
@@ -1297,10 +1297,21 @@ __device__ __forceinline__ void mom_add16(const MomIn &t, double (&v)[16])
 
 // whether the query is certain to keep its pair (and its accepted / rejected status) while the scan moves by at most
 // `guard` more: the certificate of reuse_certificate evaluated at motion m_now + guard with the distance grown by guard
-__device__ __forceinline__ bool stays_frozen(const QueryIn &q, float thr, float m_now, float guard)
+// (sharded: `in_range` = the slot holds a candidate of this rank; whether the rank OWNS it -- x inside its slab -- must not
+// change within the guard either)
+template <bool SHARD>
+__device__ __forceinline__ bool stays_frozen(const QueryIn &q, bool in_range, float thr, float m_now, float guard, float xlo, float xhi)
 {
-    if (!q.valid) return true; // no query here: nothing to evaluate, ever
-    if (!(isfinite(q.qx) && isfinite(q.qy) && isfinite(q.qz))) return true; // never has a pair (the search takes no non-finite query)
+    if (!in_range) return true; // no query here: nothing to evaluate, ever
+    if (!(isfinite(q.qx) && isfinite(q.qy) && isfinite(q.qz))) return true; // never has a pair (the search takes no non-finite query; no slab holds it)
+    if (SHARD) {
+        const float gx = guard * 1.000002f + (fabsf(q.qx) + 1.0f) * 2.6e-7f + 1.0e-6f; // the motion + the float32 roundings of x then and now
+        if (q.valid) {
+            if (!(q.qx - gx >= xlo && q.qx + gx < xhi)) return false; // may leave the slab
+        } else {
+            return q.qx + gx < xlo || q.qx - gx >= xhi; // stays some other rank's (else: may enter the slab)
+        }
+    }
     if (!(q.e > 0.0f)) return false;
     const float m = m_now + guard * 1.000002f;
     const float reach = q.e - m * 1.000002f - (fabsf(q.qx) + fabsf(q.qy) + fabsf(q.qz) + 3.0f * guard + 1.0f) * 2.6e-7f - (q.e + m) * 5.0e-7f - 1.0e-6f;
@@ -1318,11 +1329,12 @@ __device__ __forceinline__ bool stays_frozen(const QueryIn &q, float thr, float 
 //   0  the ordinary launch (same pairs, same sums, same row as k_nn_red)
 //   1  freeze launch: ordinary pairs; frozen ones into the moment row, active ones into the ordinary row and the row's list
 //   2  frozen: the scan's active queries, FZ_CAP per workgroup (wave 0: certificate, search if it fails), into the first rows; the other workgroups leave
-template <int Q>
+template <int Q, bool SHARD>
 __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
-                                                   int n, const IcpState *__restrict__ st, float thr, double *__restrict__ partials, int nblocks, float4 *__restrict__ qcache,
-                                                   int64_t cache_n, uint32_t *__restrict__ stats, const FreezeState *__restrict__ fz, double *__restrict__ mom_part,
-                                                   uint32_t *__restrict__ act_cnt, uint16_t *__restrict__ act_ids, const uint32_t *__restrict__ act_all)
+                                                   int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks,
+                                                   const uint32_t *__restrict__ own_off, float4 *__restrict__ qcache, int64_t cache_n, uint32_t *__restrict__ stats,
+                                                   const FreezeState *__restrict__ fz, double *__restrict__ mom_part, uint32_t *__restrict__ act_cnt,
+                                                   uint16_t *__restrict__ act_ids, const uint32_t *__restrict__ act_all)
 {
     constexpr int MODE = 2;
     constexpr int NREC = NREC_PLANE;
@@ -1335,6 +1347,8 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWin
     const IcpState *S = st + b;
     if (S->done) return;
     const int fmode = fz[b].mode;
+    // sharded: this rank's compact arrays of owned-query candidates, as in k_nn_red
+    const int n_live = SHARD ? (int)(own_off[b + 1] - own_off[b]) : n;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t row = (size_t)b * nblocks + bx;
     double *dst = partials + row * REC_STRIDE;
@@ -1356,8 +1370,8 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWin
 #pragma unroll
         for (int u = 0; u < Q; ++u) {
             const uint32_t i = (uint32_t)(u * 64 + lane);
-            const int slot = i < cnt ? (int)list[i] : n; // n: no query
-            P[u] = nn_pair<MODE, false, false>(g, w, X0x, X0y, X0z, n, b, S, thr, 0.0f, 0.0f, nullptr, qcache, cache_n, slot, n, &nn_ws[0], stats);
+            const int slot = i < cnt ? (int)list[i] : n_live; // n_live: no query
+            P[u] = nn_pair<MODE, false, SHARD>(g, w, X0x, X0y, X0z, n, b, S, thr, xlo, xhi, own_off, qcache, cache_n, slot, n_live, &nn_ws[0], stats);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1374,6 +1388,7 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWin
         }
         return;
     }
+    if (SHARD && bx * (BLK * Q) >= n_live) return; // the reduce kernels read only the rows that exist
     __shared__ double stage[BLK / 64][32];
     __shared__ uint32_t act_w[BLK / 64][Q];
     bool active[Q];
@@ -1388,12 +1403,12 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWin
 #pragma unroll
         for (int u = 0; u < Q; ++u) {
             const int slot = bx * (BLK * Q) + u * BLK + (int)threadIdx.x;
-            const QueryIn q = query_in<MODE, false>(X0x, X0y, X0z, n, b, S, 0.0f, 0.0f, nullptr, qcache, cache_n, true, slot, n);
+            const QueryIn q = query_in<MODE, SHARD>(X0x, X0y, X0z, n, b, S, xlo, xhi, own_off, qcache, cache_n, true, slot, n_live);
             sf::NNHit hit, seed;
             float4 tn;
             any_need = reuse_certificate(q.valid, q.qx, q.qy, q.qz, thr, m_now, q.e, q.c1, q.c2, hit, tn, seed) || any_need;
             P[u] = make_pair(q, hit, tn);
-            if (fmode == 1) active[u] = !stays_frozen(q, thr, m_now, guard);
+            if (fmode == 1) active[u] = !stays_frozen<SHARD>(q, slot < n_live, thr, m_now, guard, xlo, xhi);
         }
         fast = __ballot(any_need) == 0ull;
     }
@@ -1402,10 +1417,10 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWin
 #pragma unroll
         for (int u = 0; u < Q; ++u) {
             const int slot = bx * (BLK * Q) + u * BLK + (int)threadIdx.x;
-            P[u] = nn_pair<MODE, false, false>(g, w, X0x, X0y, X0z, n, b, S, thr, 0.0f, 0.0f, nullptr, qcache, cache_n, slot, n, &nn_ws[wv], stats);
+            P[u] = nn_pair<MODE, false, SHARD>(g, w, X0x, X0y, X0z, n, b, S, thr, xlo, xhi, own_off, qcache, cache_n, slot, n_live, &nn_ws[wv], stats);
             // (freeze launch: the classes stand as taken above -- a lane that searches here failed the plain certificate, so it
             // failed the guarded one and is active; the others' pairs are the ones the attempt found)
-            if (fmode == 1 && !attempted) active[u] = slot < n;
+            if (fmode == 1 && !attempted) active[u] = slot < n_live;
         }
     }
     if (fmode == 1) {
@@ -1593,35 +1608,39 @@ __device__ __forceinline__ void frozen_record(const double *__restrict__ mom, co
     __syncthreads();
 }
 
-// k_reduce_solve<2> for the launches that may freeze (see k_nn_red_fz); `request`: this solve may ask for a freeze launch
-__global__ __launch_bounds__(RBLK) void k_reduce_solve_fz(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, int n_src, int K,
-                                                          const ScanBox *__restrict__ boxp, FreezeState *__restrict__ fz, const double *__restrict__ mom_part,
-                                                          const uint32_t *__restrict__ act_cnt, const uint16_t *__restrict__ act_ids, uint32_t *__restrict__ act_all,
-                                                          FreezeParams fp, int request)
+struct FreezeBufs {
+    FreezeState *fz;          // nullptr: no frozen pairs in this launch
+    const double *mom_part;   // [scan][row][FZ_NMOM]
+    const uint32_t *act_cnt;  // [scan][row]
+    const uint16_t *act_ids;  // [scan][row][FZ_CAP]
+    uint32_t *act_all;        // [scan][rows x FZ_CAP]: the scan's list
+};
+
+// The reduce half of a launch that may freeze, by the scan's workgroup of RBLK threads: the record of the scan's pairs at
+// the launch's pose in rec[] (shared, REC_STRIDE) -- slab rows (every pair / the active ones) + the frozen pairs from
+// their moments; a freeze launch's moments and lists are folded and the freeze held or voided here.  `stride`: slab rows
+// per scan, `rows`: the rows an ordinary launch of this scan writes.  What a rank freezes is its own business (sharded: its
+// owned queries): the record it contributes is the same sum either way.
+__device__ __forceinline__ void freeze_fold(const IcpState *S, FreezeState *F, int b, const double *__restrict__ partials, int stride, int rows, const FreezeBufs &fb, double *rec)
 {
-    const int b = blockIdx.x;
-    IcpState *S = st + b;
-    if (S->done) return;
-    FreezeState *F = fz + b;
     const int fmode = F->mode;
-    __shared__ double rec[REC_STRIDE];
     __shared__ double mom[FZ_NMOM];
     __shared__ double D[12];
-    __shared__ unsigned long long act_total;
     __shared__ uint32_t act_worst;
+    __shared__ uint32_t act_total;
     // frozen: only the first rows were written, by the workgroups that had a piece of the scan's active list
-    const int rows_live = fmode == 2 ? (int)((F->n_active + FZ_CAP - 1) / FZ_CAP) : nblocks;
-    reduce_partials<NREC_PLANE>(partials + (size_t)b * nblocks * REC_STRIDE, rows_live, rec);
+    const int rows_live = fmode == 2 ? (int)((F->n_active + FZ_CAP - 1) / FZ_CAP) : rows;
+    reduce_partials<NREC_PLANE>(partials + (size_t)b * stride * REC_STRIDE, rows_live, rec);
     if (fmode == 1) {
-        reduce_columns<FZ_NMOM, FZ_NMOM>(mom_part + (size_t)b * nblocks * FZ_NMOM, nblocks, mom);
+        reduce_columns<FZ_NMOM, FZ_NMOM>(fb.mom_part + (size_t)b * stride * FZ_NMOM, rows, mom);
         // the rows' active lists -> one list per scan (row order, slot order inside a row): where each row's piece starts ...
         __shared__ uint32_t pre[RBLK];
-        if (threadIdx.x == 0) { act_total = 0ull; act_worst = 0u; }
+        if (threadIdx.x == 0) act_worst = 0u;
         __syncthreads();
         uint32_t run = 0;
-        for (int r0 = 0; r0 < nblocks; r0 += RBLK) {
+        for (int r0 = 0; r0 < rows; r0 += RBLK) {
             const int r = r0 + (int)threadIdx.x;
-            const uint32_t c = r < nblocks ? act_cnt[(size_t)b * nblocks + r] : 0u;
+            const uint32_t c = r < rows ? fb.act_cnt[(size_t)b * stride + r] : 0u;
             pre[threadIdx.x] = c;
             __syncthreads();
             for (int off = 1; off < RBLK; off <<= 1) { // inclusive scan of the chunk
@@ -1632,12 +1651,12 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve_fz(IcpState *__restrict__
             }
             const uint32_t start = run + pre[threadIdx.x] - c;
             if (c > (uint32_t)FZ_CAP) atomicMax(&act_worst, c);
-            if (r < nblocks && c <= (uint32_t)FZ_CAP) // ... and the copy (a row that overflowed: the freeze does not hold, the list is not used)
-                for (uint32_t i = 0; i < c; ++i) act_all[(size_t)b * nblocks * FZ_CAP + start + i] = (uint32_t)r * (uint32_t)(BLK * SF_WIDE_QPL) + act_ids[((size_t)b * nblocks + r) * FZ_CAP + i];
+            if (r < rows && c <= (uint32_t)FZ_CAP) // ... and the copy (a row that overflowed: the freeze does not hold, the list is not used)
+                for (uint32_t i = 0; i < c; ++i) fb.act_all[(size_t)b * stride * FZ_CAP + start + i] = (uint32_t)r * (uint32_t)(BLK * SF_WIDE_QPL) + fb.act_ids[((size_t)b * stride + r) * FZ_CAP + i];
             run += pre[RBLK - 1];
             __syncthreads();
         }
-        if (threadIdx.x == 0) act_total = (unsigned long long)run;
+        if (threadIdx.x == 0) act_total = run;
         __syncthreads();
     } else if (fmode == 2) {
         if (threadIdx.x < FZ_NMOM) mom[threadIdx.x] = F->mom[threadIdx.x];
@@ -1659,14 +1678,7 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve_fz(IcpState *__restrict__
         frozen_record(mom, D, rec);
     }
     if (threadIdx.x == 0) {
-        for (int c = 0; c < NREC_PLANE; ++c) S->rec[c] = rec[c];
-        double To[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) To[i] = S->T[i];
-        const double m0 = S->motion;
-        solve_plane(S, rec, n_src, K);
-        track_motion(S, To, boxp[b]);
-        const double m1 = S->motion, dm = m1 - m0;
+        F->launch_mode = fmode;
         if (fmode == 1) {
             F->n_active = (int64_t)act_total;
             if (act_worst > (uint32_t)FZ_CAP) { // a row could not list its active queries: this launch was an ordinary one in two parts, nothing is frozen
@@ -1675,22 +1687,50 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve_fz(IcpState *__restrict__
             } else {
                 F->mode = 2;
                 F->froze += 1;
-                F->motion0 = m0;
-                for (int i = 0; i < 12; ++i) F->Tf[i] = To[i];
+                F->motion0 = S->motion;
+                for (int i = 0; i < 12; ++i) F->Tf[i] = S->T[i];
                 for (int i = 0; i < FZ_NMOM; ++i) F->mom[i] = mom[i];
             }
         }
-        if (F->mode == 2 && !(m1 - F->motion0 <= (double)F->guard * 0.98)) { // the next launch's pose is beyond what the frozen queries were cleared for
-            F->mode = 0;
-            F->tries += 1;
-            F->thawed += 1;
-        }
-        if (F->mode == 0 && fmode == 0 && request && !S->done && F->tries < fp.max_tries) {
-            // a guard of a few times the last update's motion (ICP steps shrink geometrically); while that is still large the
-            // active lists would be long (or overflow: a freeze launch for nothing) -- wait for a later launch
-            const float gd = fmaxf((float)dm * fp.guard_scale, fp.guard_min);
-            if (gd <= fp.guard_max) { F->guard = gd; F->mode = 1; }
-        }
+    }
+    __syncthreads();
+}
+
+// the solve half's bookkeeping, by the lane that solved (m0 / m1: IcpState::motion before / after the pose update)
+__device__ __forceinline__ void freeze_after_update(const IcpState *S, FreezeState *F, double m0, double m1, const FreezeParams &fp, int request)
+{
+    if (F->mode == 2 && !(m1 - F->motion0 <= (double)F->guard * 0.98)) { // the next launch's pose is beyond what the frozen queries were cleared for
+        F->mode = 0;
+        F->tries += 1;
+        F->thawed += 1;
+    }
+    if (F->mode == 0 && F->launch_mode == 0 && request && !S->done && F->tries < fp.max_tries) {
+        // a guard of a few times the last update's motion (ICP steps shrink geometrically); while that is still large the
+        // active lists would be long (or overflow: a freeze launch for nothing) -- wait for a later launch
+        const float gd = fmaxf((float)(m1 - m0) * fp.guard_scale, fp.guard_min);
+        if (gd <= fp.guard_max) { F->guard = gd; F->mode = 1; }
+    }
+}
+
+// k_reduce_solve<2> for the launches that may freeze (see k_nn_red_fz); `request`: this solve may ask for a freeze launch
+__global__ __launch_bounds__(RBLK) void k_reduce_solve_fz(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, int n_src, int K,
+                                                          const ScanBox *__restrict__ boxp, FreezeBufs fb, FreezeParams fp, int request)
+{
+    const int b = blockIdx.x;
+    IcpState *S = st + b;
+    if (S->done) return;
+    FreezeState *F = fb.fz + b;
+    __shared__ double rec[REC_STRIDE];
+    freeze_fold(S, F, b, partials, nblocks, nblocks, fb, rec);
+    if (threadIdx.x == 0) {
+        for (int c = 0; c < NREC_PLANE; ++c) S->rec[c] = rec[c];
+        double To[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) To[i] = S->T[i];
+        const double m0 = S->motion;
+        solve_plane(S, rec, n_src, K);
+        track_motion(S, To, boxp[b]);
+        freeze_after_update(S, F, m0, S->motion, fp, request);
     }
 }
 
@@ -1699,13 +1739,13 @@ __global__ void k_fz_init(FreezeState *__restrict__ fz, int batch)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     FreezeState *F = fz + b;
-    F->mode = 0; F->tries = 0; F->froze = 0; F->thawed = 0; F->n_active = 0; F->guard = 0.0f; F->pad = 0.0f; F->motion0 = 0.0;
+    F->mode = 0; F->tries = 0; F->froze = 0; F->thawed = 0; F->n_active = 0; F->guard = 0.0f; F->launch_mode = 0; F->motion0 = 0.0;
 }
 
 // multi-GPU split: reduce into the exchange buffer, all-reduce outside, then solve
 template <int MODE>
 __global__ __launch_bounds__(RBLK) void k_reduce_only(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, double *__restrict__ xchg,
-                                                      const uint32_t *__restrict__ own_off, int qpl)
+                                                      const uint32_t *__restrict__ own_off, int qpl, FreezeBufs fb)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x;
@@ -1715,12 +1755,14 @@ __global__ __launch_bounds__(RBLK) void k_reduce_only(IcpState *__restrict__ st,
         return;
     }
     const int rows = own_off ? (int)((own_off[b + 1] - own_off[b] + BLK * qpl - 1) / (BLK * qpl)) : nblocks; // sharded: workgroups beyond the owned queries wrote nothing
-    reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, rows, rec);
+    if (MODE == 2 && fb.fz) freeze_fold(st + b, fb.fz + b, b, partials, nblocks, rows, fb, rec);
+    else reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, rows, rec);
     if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = rec[threadIdx.x];
 }
 
 template <int MODE>
-__global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict__ xchg, int n_src, int K, int batch, const ScanBox *__restrict__ boxp, float margin)
+__global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict__ xchg, int n_src, int K, int batch, const ScanBox *__restrict__ boxp, float margin,
+                             FreezeState *__restrict__ fz, FreezeParams fp, int request)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1735,10 +1777,12 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
     double To[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) To[i] = S->T[i];
+    const double m0 = S->motion;
     if (MODE == 1) solve_o3d(S, rec, n_src, 0, K);
     else solve_plane(S, rec, n_src, K);
     track_motion(S, To, boxp[b]);
     if (margin > 0.0f && !S->done) own_check_motion(S, boxp[b], margin); // sharded path only (the scan's own box, computed on the device)
+    if (MODE == 2 && fz) freeze_after_update(S, fz + b, m0, S->motion, fp, request);
 }
 
 // ------------------------------------------------------------------ sharded step over the P2P transport, two kernels
@@ -1749,7 +1793,7 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
 // record.  Protocol, fences and failure behaviour as k_p2p_allreduce (sf_shard.cpp); flags are per scan (sf_p2p.hpp).
 template <int MODE>
 __global__ __launch_bounds__(RBLK) void k_reduce_publish(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, const uint32_t *__restrict__ own_off, int qpl,
-                                                         sf::P2pView v)
+                                                         sf::P2pView v, FreezeBufs fb)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x, tid = (int)threadIdx.x, R = v.peers.nranks, me = v.peers.rank, par = (int)(v.seq & 1ull);
@@ -1762,7 +1806,8 @@ __global__ __launch_bounds__(RBLK) void k_reduce_publish(IcpState *__restrict__ 
         __syncthreads();
     } else {
         const int rows = own_off ? (int)((own_off[b + 1] - own_off[b] + BLK * qpl - 1) / (BLK * qpl)) : nblocks;
-        reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, rows, rec); // (ends with a barrier)
+        if (MODE == 2 && fb.fz) freeze_fold(st + b, fb.fz + b, b, partials, nblocks, rows, fb, rec);
+        else reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, rows, rec); // (both end with a barrier)
     }
     if (dead) return; // the communicator is poisoned: k_gather_solve reports it
     if (tid < REC_STRIDE * R) {
@@ -1780,7 +1825,8 @@ __global__ __launch_bounds__(RBLK) void k_reduce_publish(IcpState *__restrict__ 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k_gather_solve(IcpState *__restrict__ st, int n_src, int K, const ScanBox *__restrict__ boxp, float margin, sf::P2pView v)
+__global__ __launch_bounds__(64) void k_gather_solve(IcpState *__restrict__ st, int n_src, int K, const ScanBox *__restrict__ boxp, float margin, sf::P2pView v,
+                                                     FreezeState *__restrict__ fz, FreezeParams fp, int request)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
     const int b = blockIdx.x, lane = (int)threadIdx.x, R = v.peers.nranks, me = v.peers.rank, par = (int)(v.seq & 1ull);
@@ -1825,10 +1871,12 @@ __global__ __launch_bounds__(64) void k_gather_solve(IcpState *__restrict__ st, 
         double To[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) To[i] = S->T[i];
+        const double m0 = S->motion;
         if (MODE == 1) solve_o3d(S, rec, n_src, 0, K);
         else solve_plane(S, rec, n_src, K);
         track_motion(S, To, boxp[b]);
         if (margin > 0.0f && !S->done) own_check_motion(S, boxp[b], margin);
+        if (MODE == 2 && fz) freeze_after_update(S, fz + b, m0, S->motion, fp, request);
     }
 }
 
@@ -2474,6 +2522,7 @@ struct sf_icp {
     int freeze = 1;                 // sf_icp_set_freeze: 0 off, 1 when the batch is large enough to gain (FREEZE_AUTO_MIN_QUERIES), 2 always
     FreezeParams fz_prm{8.0f, 2.0e-5f, 3.0e-4f, 3};
     int fz_from = 5;                // launch index of the first launch that may be a freeze launch
+    int fz_step = 0;                // stepping paths: launches since the pass began
     sf::DevBuf fz_state, fz_part, fz_cnt, fz_ids, fz_all;
     int64_t nn_stats_used = 0;
     static constexpr int64_t NN_STATS_CAP = 1024;
@@ -2711,19 +2760,21 @@ void launch_nn_red(sf_icp *icp, bool sharded = false)
 #undef SF_LAUNCH_NNRED
 }
 
-// frozen pairs: P2PLANE launch list of wide scans with the neighbour reuse on, whole map, unsharded
+// frozen pairs: P2PLANE launch list of wide scans with the neighbour reuse on, whole map; sharded: each rank freezes its own
+// owned queries (what it contributes to the all-reduced record is the same sum either way)
 bool freeze_on(const sf_icp *icp, int mode)
 {
     // a frozen launch costs the latency of one search (31 us measured) + the solve, whatever the batch: below ~4 M queries per
     // launch a verifying launch is cheaper than that (one 200 k-point scan: 0.39 ms per alignment without, 0.48 ms with)
-    const bool wanted = icp->freeze == 2 || (icp->freeze == 1 && icp->n * icp->batch >= FREEZE_AUTO_MIN_QUERIES);
-    return mode == SF_ICP_P2PLANE && wanted && icp->reuse && icp->qpl == SF_WIDE_QPL && icp->map->window.kind == 0 && !icp->shard &&
-           icp->prm.num_iters > icp->fz_from + 1 && icp->fz_from >= VERIFY_FROM_SEARCH;
+    const int64_t queries = icp->shard ? icp->own_total : icp->n * icp->batch;
+    const bool wanted = icp->freeze == 2 || (icp->freeze == 1 && queries >= FREEZE_AUTO_MIN_QUERIES);
+    return mode == SF_ICP_P2PLANE && wanted && icp->reuse && icp->qpl == SF_WIDE_QPL && icp->map->window.kind == 0 && icp->prm.num_iters > icp->fz_from + 1 &&
+           icp->fz_from >= VERIFY_FROM_SEARCH;
 }
 
 int freeze_alloc(sf_icp *icp)
 {
-    const size_t rows = (size_t)icp->batch * (size_t)icp->nblocks_nn;
+    const size_t rows = (size_t)icp->batch * (size_t)std::max(icp->nblocks_nn, icp->shard ? icp->own_nblocks : 0);
     SF_TRY(icp->fz_state.reserve(sizeof(FreezeState) * (size_t)icp->batch));
     SF_TRY(icp->fz_part.reserve(sizeof(double) * FZ_NMOM * rows));
     SF_TRY(icp->fz_cnt.reserve(sizeof(uint32_t) * rows));
@@ -2732,17 +2783,45 @@ int freeze_alloc(sf_icp *icp)
     return SF_OK;
 }
 
-void launch_nn_red_fz(sf_icp *icp)
+FreezeBufs freeze_bufs(sf_icp *icp, bool on)
+{
+    FreezeBufs fb;
+    fb.fz = on ? icp->fz_state.as<FreezeState>() : nullptr;
+    fb.mom_part = icp->fz_part.as<double>();
+    fb.act_cnt = icp->fz_cnt.as<uint32_t>();
+    fb.act_ids = icp->fz_ids.as<uint16_t>();
+    fb.act_all = icp->fz_all.as<uint32_t>();
+    return fb;
+}
+
+void launch_nn_red_fz(sf_icp *icp, bool sharded = false)
 {
     sf_map *m = icp->map;
-    const int nb = icp->nblocks_nn;
+    const int nb = sharded ? icp->own_nblocks : icp->nblocks_nn;
     const dim3 grid((unsigned)((nb + 7) & ~7), (unsigned)icp->batch), blk(BLK);
     ProfScope ps(icp);
     uint32_t *stats = nullptr;
     if (icp->profiling && icp->nn_stats.p && icp->nn_stats_used < sf_icp::NN_STATS_CAP) stats = icp->nn_stats.as<uint32_t>() + 2 * NN_STATS_SHARDS * icp->nn_stats_used++;
-    hipLaunchKernelGGL((k_nn_red_fz<SF_WIDE_QPL>), grid, blk, 0, icp->ctx->stream, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n,
-                       icp->state.as<IcpState>(), o3d_thr(icp), icp->partials.as<double>(), nb, icp->qcache.as<float4>(), icp->cache_n, stats,
-                       icp->fz_state.as<FreezeState>(), icp->fz_part.as<double>(), icp->fz_cnt.as<uint32_t>(), icp->fz_ids.as<uint16_t>(), icp->fz_all.as<uint32_t>());
+#define SF_LAUNCH_FZ(S)                                                                                                                                               \
+    hipLaunchKernelGGL((k_nn_red_fz<SF_WIDE_QPL, S>), grid, blk, 0, icp->ctx->stream, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n,         \
+                       icp->state.as<IcpState>(), o3d_thr(icp), icp->xlo, icp->xhi, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qcache.as<float4>(), \
+                       icp->cache_n, stats, icp->fz_state.as<FreezeState>(), icp->fz_part.as<double>(), icp->fz_cnt.as<uint32_t>(), icp->fz_ids.as<uint16_t>(),           \
+                       icp->fz_all.as<uint32_t>())
+    if (sharded) SF_LAUNCH_FZ(true);
+    else SF_LAUNCH_FZ(false);
+#undef SF_LAUNCH_FZ
+}
+
+// the stepping paths (sharded loop, sf_icp_step_begin / _end): which launch of the pass this is
+bool freeze_nn_now(const sf_icp *icp, int mode) { return freeze_on(icp, mode) && icp->fz_step >= icp->fz_from; }
+bool freeze_solve_now(const sf_icp *icp, int mode) { return freeze_on(icp, mode) && icp->fz_step + 1 >= icp->fz_from; }
+int freeze_start_pass(sf_icp *icp, int mode)
+{
+    icp->fz_step = 0;
+    if (!freeze_on(icp, mode)) return SF_OK;
+    SF_TRY(freeze_alloc(icp));
+    hipLaunchKernelGGL(k_fz_init, dim3(nblk(icp->batch, 64)), dim3(64), 0, icp->ctx->stream, icp->fz_state.as<FreezeState>(), icp->batch);
+    return SF_OK;
 }
 
 // A hipMemcpyAsync from pageable memory makes the host wait until the stream has reached it -- that would turn every
@@ -2803,8 +2882,8 @@ int enqueue_align(sf_icp *icp, int mode)
             if (fz && k >= icp->fz_from) launch_nn_red_fz(icp);
             else launch_nn_red<2>(icp);
             if (fz && k + 1 >= icp->fz_from)
-                hipLaunchKernelGGL(k_reduce_solve_fz, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, K, icp->d_boxes.as<ScanBox>(), icp->fz_state.as<FreezeState>(),
-                                   icp->fz_part.as<double>(), icp->fz_cnt.as<uint32_t>(), icp->fz_ids.as<uint16_t>(), icp->fz_all.as<uint32_t>(), icp->fz_prm, (int)(k + 2 < K));
+                hipLaunchKernelGGL(k_reduce_solve_fz, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, K, icp->d_boxes.as<ScanBox>(), freeze_bufs(icp, true), icp->fz_prm,
+                                   (int)(k + 2 < K));
             else
                 hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K, icp->d_boxes.as<ScanBox>());
         }
@@ -3501,6 +3580,7 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
         SF_TRY(order_queries(icp, mode));
         SF_TRY(reuse_reset(icp, icp->n * icp->batch));
     }
+    if (first) SF_TRY(freeze_start_pass(icp, mode));
     double *x = reinterpret_cast<double *>(sf_icp_exchange_ptr(icp, nullptr));
     hipStream_t s = icp->ctx->stream;
     const int nb = icp->shard ? icp->own_nblocks : icp->nblocks_nn;
@@ -3508,11 +3588,13 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
     if (mode == SF_ICP_O3D_P2P) {
         launch_nn_red<1>(icp, icp->shard);
         ProfScope ps(icp, SF_PROF_REDUCE);
-        hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl);
+        hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl, freeze_bufs(icp, false));
     } else {
-        launch_nn_red<2>(icp, icp->shard);
+        if (freeze_nn_now(icp, mode)) launch_nn_red_fz(icp, icp->shard);
+        else launch_nn_red<2>(icp, icp->shard);
         ProfScope ps(icp, SF_PROF_REDUCE);
-        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl);
+        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl,
+                           freeze_bufs(icp, freeze_nn_now(icp, mode)));
     }
     SF_HIP(hipGetLastError());
     return SF_OK;
@@ -3527,9 +3609,13 @@ extern "C" int sf_icp_step_end(sf_icp *icp, int mode, int last)
     const int K = icp->prm.num_iters;
     ProfScope ps(icp, SF_PROF_SOLVE);
     if (mode == SF_ICP_O3D_P2P)
-        hipLaunchKernelGGL(k_solve_only<1>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->d_boxes.as<ScanBox>(), icp->shard ? icp->own_margin : 0.0f);
+        hipLaunchKernelGGL(k_solve_only<1>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->d_boxes.as<ScanBox>(),
+                           icp->shard ? icp->own_margin : 0.0f, (FreezeState *)nullptr, icp->fz_prm, 0);
     else
-        hipLaunchKernelGGL(k_solve_only<2>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->d_boxes.as<ScanBox>(), icp->shard ? icp->own_margin : 0.0f);
+        hipLaunchKernelGGL(k_solve_only<2>, dim3(nblk(icp->batch, 64)), dim3(64), 0, s, icp->state.as<IcpState>(), x, (int)icp->n, K, icp->batch, icp->d_boxes.as<ScanBox>(),
+                           icp->shard ? icp->own_margin : 0.0f, freeze_solve_now(icp, mode) ? icp->fz_state.as<FreezeState>() : (FreezeState *)nullptr, icp->fz_prm,
+                           (int)(icp->fz_step + 2 < K));
+    icp->fz_step += 1;
     SF_HIP(hipGetLastError());
     return SF_OK;
 }
@@ -3600,21 +3686,26 @@ int shard_step_p2p(sf_icp *icp, int mode, int first, const sf::P2pView &view)
     icp->last_fused = false;
     if (first == 1) SF_TRY(launch_state_init(icp));
     if (first) SF_TRY(shard_build(icp, first == 2));
+    if (first) SF_TRY(freeze_start_pass(icp, mode));
     hipStream_t s = icp->ctx->stream;
     IcpState *st = icp->state.as<IcpState>();
     const int nb = icp->own_nblocks, B = icp->batch, K = icp->prm.num_iters;
+    const bool fz_nn = freeze_nn_now(icp, mode), fz_solve = freeze_solve_now(icp, mode);
     if (mode == SF_ICP_O3D_P2P) launch_nn_red<1>(icp, true);
+    else if (fz_nn) launch_nn_red_fz(icp, true);
     else launch_nn_red<2>(icp, true);
     {
         ProfScope ps(icp, SF_PROF_REDUCE);
-        if (mode == SF_ICP_O3D_P2P) hipLaunchKernelGGL(k_reduce_publish<1>, dim3(B), dim3(RBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qpl, view);
-        else hipLaunchKernelGGL(k_reduce_publish<2>, dim3(B), dim3(RBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qpl, view);
+        if (mode == SF_ICP_O3D_P2P) hipLaunchKernelGGL(k_reduce_publish<1>, dim3(B), dim3(RBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qpl, view, freeze_bufs(icp, false));
+        else hipLaunchKernelGGL(k_reduce_publish<2>, dim3(B), dim3(RBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qpl, view, freeze_bufs(icp, fz_nn));
     }
     {
         ProfScope ps(icp, SF_PROF_COLLECTIVE); // the wait for the peers' records AND the solve
-        if (mode == SF_ICP_O3D_P2P) hipLaunchKernelGGL(k_gather_solve<1>, dim3(B), dim3(64), 0, s, st, (int)icp->n, K, icp->d_boxes.as<ScanBox>(), icp->own_margin, view);
-        else hipLaunchKernelGGL(k_gather_solve<2>, dim3(B), dim3(64), 0, s, st, (int)icp->n, K, icp->d_boxes.as<ScanBox>(), icp->own_margin, view);
+        if (mode == SF_ICP_O3D_P2P) hipLaunchKernelGGL(k_gather_solve<1>, dim3(B), dim3(64), 0, s, st, (int)icp->n, K, icp->d_boxes.as<ScanBox>(), icp->own_margin, view, (FreezeState *)nullptr, icp->fz_prm, 0);
+        else hipLaunchKernelGGL(k_gather_solve<2>, dim3(B), dim3(64), 0, s, st, (int)icp->n, K, icp->d_boxes.as<ScanBox>(), icp->own_margin, view,
+                                fz_solve ? icp->fz_state.as<FreezeState>() : (FreezeState *)nullptr, icp->fz_prm, (int)(icp->fz_step + 2 < K));
     }
+    icp->fz_step += 1;
     SF_HIP(hipGetLastError());
     return SF_OK;
 }
