@@ -1329,24 +1329,43 @@ __device__ __forceinline__ bool stays_frozen(const QueryIn &q, bool in_range, fl
 //   0  the ordinary launch (same pairs, same sums, same row as k_nn_red)
 //   1  freeze launch: ordinary pairs; frozen ones into the moment row, active ones into the ordinary row and the row's list
 //   2  frozen: the scan's active queries, FZ_CAP per workgroup (wave 0: certificate, search if it fails), into the first rows; the other workgroups leave
+struct FzArgs { // what k_nn_red_fz and k_nn_red_fz_few pass on to the row
+    const float *X0x, *X0y, *X0z;
+    int n;
+    const IcpState *st;
+    float thr, xlo, xhi;
+    double *partials;
+    int nblocks;
+    const uint32_t *own_off;
+    float4 *qcache;
+    int64_t cache_n;
+    uint32_t *stats;
+    const FreezeState *fz;
+    double *mom_part;
+    uint32_t *act_cnt;
+    uint16_t *act_ids;
+    const uint32_t *act_all;
+};
+
+// slab row bx of scan b (not done) in mode fmode; every `return` is taken by whole waves, and outside the frozen mode by the
+// whole workgroup
 template <int Q, bool SHARD>
-__global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
-                                                   int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks,
-                                                   const uint32_t *__restrict__ own_off, float4 *__restrict__ qcache, int64_t cache_n, uint32_t *__restrict__ stats,
-                                                   const FreezeState *__restrict__ fz, double *__restrict__ mom_part, uint32_t *__restrict__ act_cnt,
-                                                   uint16_t *__restrict__ act_ids, const uint32_t *__restrict__ act_all)
+__device__ __forceinline__ void nn_red_fz_row(const SfGrid &g, const SfWindow &w, const FzArgs &A, int b, int bx, int fmode)
 {
     constexpr int MODE = 2;
     constexpr int NREC = NREC_PLANE;
     static_assert(FZ_CAP == 64 * Q, "wave 0 takes FZ_CAP active queries in Q rounds of 64");
-    const int L = blockIdx.y * gridDim.x + blockIdx.x; // placement as k_nn_red
-    const int kk = L >> 3;
-    const int b = kk % (int)gridDim.y;
-    const int bx = (L & 7) * ((int)gridDim.x >> 3) + kk / (int)gridDim.y;
-    if (bx >= nblocks) return;
-    const IcpState *S = st + b;
-    if (S->done) return;
-    const int fmode = fz[b].mode;
+    const float *__restrict__ X0x = A.X0x, *__restrict__ X0y = A.X0y, *__restrict__ X0z = A.X0z;
+    const int n = A.n, nblocks = A.nblocks;
+    const float thr = A.thr, xlo = A.xlo, xhi = A.xhi;
+    double *__restrict__ partials = A.partials, *__restrict__ mom_part = A.mom_part;
+    const uint32_t *__restrict__ own_off = A.own_off, *__restrict__ act_all = A.act_all;
+    float4 *__restrict__ qcache = A.qcache;
+    const int64_t cache_n = A.cache_n;
+    uint32_t *__restrict__ stats = A.stats, *__restrict__ act_cnt = A.act_cnt;
+    uint16_t *__restrict__ act_ids = A.act_ids;
+    const FreezeState *__restrict__ fz = A.fz;
+    const IcpState *S = A.st + b;
     // sharded: this rank's compact arrays of owned-query candidates, as in k_nn_red
     const int n_live = SHARD ? (int)(own_off[b + 1] - own_off[b]) : n;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1355,13 +1374,11 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWin
     __shared__ sf::WaveNN nn_ws[BLK / 64];
     LanePair P[Q];
     if (fmode == 2) {
-        // the scan's active queries, FZ_CAP per workgroup from the scan's list (k_reduce_solve_fz wrote it, in row and slot
-        // order), taken by wave 0 in Q rounds; workgroups beyond the list leave at once, k_reduce_solve_fz adds only the rows
-        // that were written.  (Measured: four waves side by side with 64 each, and a fixed grid of resident workgroups
-        // walking the rows with the per-scan state in LDS, are both slower -- 33.8 / 32.1 against 31.3 us per launch, and
-        // the freeze launch 409 against 326 us as a fixed grid.  What a frozen launch costs is the latency of ONE search:
-        // the few queries whose neighbour and runner-up are closer together than the certificate's rounding margins search in
-        // every launch.)
+        // the scan's active queries, FZ_CAP per workgroup from the scan's list (the reduce kernel wrote it, in row and slot
+        // order), taken by wave 0 in Q rounds; workgroups beyond the list leave at once, the reduce kernel adds only the rows
+        // that were written.  (Measured as a full grid, 31.3 us per launch: four waves side by side with 64 each 33.8, a
+        // fixed grid of resident workgroups walking the rows with the per-scan state in LDS 32.1 -- and 13 us with this path
+        // returning at once: the dispatch of 25 000 workgroups that find their scan frozen.  Hence k_nn_red_fz_few, 19 us.)
         if (wv != 0) return;
         const int64_t total = fz[b].n_active, first = (int64_t)bx * FZ_CAP;
         if (first >= total) return;
@@ -1495,6 +1512,45 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWin
     if (threadIdx.x < FZ_NMOM) {
         const int c = threadIdx.x;
         mom_part[row * FZ_NMOM + c] = ((mstage[0][c] + mstage[1][c]) + mstage[2][c]) + mstage[3][c];
+    }
+}
+
+// one workgroup per slab row, placed as k_nn_red's: the launch in which scans freeze (and any launch that may have to treat
+// every query the ordinary way at full speed)
+template <int Q, bool SHARD>
+__global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWindow w, FzArgs A)
+{
+    const int L = blockIdx.y * gridDim.x + blockIdx.x; // placement as k_nn_red
+    const int kk = L >> 3;
+    const int b = kk % (int)gridDim.y;
+    const int bx = (L & 7) * ((int)gridDim.x >> 3) + kk / (int)gridDim.y;
+    if (bx >= A.nblocks) return;
+    if (A.st[b].done) return;
+    nn_red_fz_row<Q, SHARD>(g, w, A, b, bx, A.fz[b].mode);
+}
+
+// The launches AFTER the first chance to freeze: FZ_FEW workgroups per scan.  A frozen scan needs one workgroup per 128
+// active queries (0.2 % of the queries here: 4 of its 391 rows) -- as a full grid the other 25 000 workgroups of a 64-scan
+// launch cost 13 us just to be dispatched, find the scan frozen and leave (measured: 31 us per launch, 13 of them with the
+// row function returning at once).  A scan that is NOT frozen (its freeze launch was voided, it thawed, or the last update
+// was still too large to ask) is walked by its FZ_FEW workgroups row by row, stride FZ_FEW: correct, at roughly 3/4 of the
+// full grid's speed.  grid (FZ_FEW, batch): workgroup r of every scan runs on XCD r % 8 and takes the rows = r (mod FZ_FEW).
+constexpr int FZ_FEW = 16;
+template <int Q, bool SHARD>
+__global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz_few(SfGrid g, SfWindow w, FzArgs A)
+{
+    const int r = (int)blockIdx.x, b = (int)blockIdx.y;
+    if (A.st[b].done) return;
+    const int fmode = A.fz[b].mode;
+    if (fmode == 2) {
+        if (threadIdx.x >= 64) return; // wave 0 takes the pieces
+        const int64_t total = A.fz[b].n_active;
+        for (int bx = r; (int64_t)bx * FZ_CAP < total; bx += FZ_FEW) nn_red_fz_row<Q, SHARD>(g, w, A, b, bx, 2);
+        return;
+    }
+    for (int bx = r; bx < A.nblocks; bx += FZ_FEW) {
+        nn_red_fz_row<Q, SHARD>(g, w, A, b, bx, fmode);
+        __syncthreads(); // the row's LDS (search state, reduction stages, list counters) is free again
     }
 }
 
@@ -2794,22 +2850,38 @@ FreezeBufs freeze_bufs(sf_icp *icp, bool on)
     return fb;
 }
 
-void launch_nn_red_fz(sf_icp *icp, bool sharded = false)
+// few: FZ_FEW workgroups per scan (k_nn_red_fz_few: the launches after the first chance to freeze)
+void launch_nn_red_fz(sf_icp *icp, bool sharded, bool few)
 {
     sf_map *m = icp->map;
     const int nb = sharded ? icp->own_nblocks : icp->nblocks_nn;
-    const dim3 grid((unsigned)((nb + 7) & ~7), (unsigned)icp->batch), blk(BLK);
+    const dim3 grid_full((unsigned)((nb + 7) & ~7), (unsigned)icp->batch), grid_few((unsigned)FZ_FEW, (unsigned)icp->batch), blk(BLK);
     ProfScope ps(icp);
-    uint32_t *stats = nullptr;
-    if (icp->profiling && icp->nn_stats.p && icp->nn_stats_used < sf_icp::NN_STATS_CAP) stats = icp->nn_stats.as<uint32_t>() + 2 * NN_STATS_SHARDS * icp->nn_stats_used++;
-#define SF_LAUNCH_FZ(S)                                                                                                                                               \
-    hipLaunchKernelGGL((k_nn_red_fz<SF_WIDE_QPL, S>), grid, blk, 0, icp->ctx->stream, m->grid, m->window, src(icp, 0), src(icp, 1), src(icp, 2), (int)icp->n,         \
-                       icp->state.as<IcpState>(), o3d_thr(icp), icp->xlo, icp->xhi, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qcache.as<float4>(), \
-                       icp->cache_n, stats, icp->fz_state.as<FreezeState>(), icp->fz_part.as<double>(), icp->fz_cnt.as<uint32_t>(), icp->fz_ids.as<uint16_t>(),           \
-                       icp->fz_all.as<uint32_t>())
-    if (sharded) SF_LAUNCH_FZ(true);
-    else SF_LAUNCH_FZ(false);
-#undef SF_LAUNCH_FZ
+    FzArgs A;
+    A.X0x = src(icp, 0); A.X0y = src(icp, 1); A.X0z = src(icp, 2);
+    A.n = (int)icp->n;
+    A.st = icp->state.as<IcpState>();
+    A.thr = o3d_thr(icp); A.xlo = icp->xlo; A.xhi = icp->xhi;
+    A.partials = icp->partials.as<double>();
+    A.nblocks = nb;
+    A.own_off = icp->own_off.as<uint32_t>();
+    A.qcache = icp->qcache.as<float4>();
+    A.cache_n = icp->cache_n;
+    A.stats = nullptr;
+    if (icp->profiling && icp->nn_stats.p && icp->nn_stats_used < sf_icp::NN_STATS_CAP) A.stats = icp->nn_stats.as<uint32_t>() + 2 * NN_STATS_SHARDS * icp->nn_stats_used++;
+    A.fz = icp->fz_state.as<FreezeState>();
+    A.mom_part = icp->fz_part.as<double>();
+    A.act_cnt = icp->fz_cnt.as<uint32_t>();
+    A.act_ids = icp->fz_ids.as<uint16_t>();
+    A.act_all = icp->fz_all.as<uint32_t>();
+    hipStream_t s = icp->ctx->stream;
+    if (few) {
+        if (sharded) hipLaunchKernelGGL((k_nn_red_fz_few<SF_WIDE_QPL, true>), grid_few, blk, 0, s, m->grid, m->window, A);
+        else hipLaunchKernelGGL((k_nn_red_fz_few<SF_WIDE_QPL, false>), grid_few, blk, 0, s, m->grid, m->window, A);
+    } else {
+        if (sharded) hipLaunchKernelGGL((k_nn_red_fz<SF_WIDE_QPL, true>), grid_full, blk, 0, s, m->grid, m->window, A);
+        else hipLaunchKernelGGL((k_nn_red_fz<SF_WIDE_QPL, false>), grid_full, blk, 0, s, m->grid, m->window, A);
+    }
 }
 
 // the stepping paths (sharded loop, sf_icp_step_begin / _end): which launch of the pass this is
@@ -2879,7 +2951,7 @@ int enqueue_align(sf_icp *icp, int mode)
             hipLaunchKernelGGL(k_fz_init, dim3(nblk(B, 64)), dim3(64), 0, s, icp->fz_state.as<FreezeState>(), B);
         }
         for (int k = 0; k < K; ++k) {
-            if (fz && k >= icp->fz_from) launch_nn_red_fz(icp);
+            if (fz && k >= icp->fz_from) launch_nn_red_fz(icp, false, k > icp->fz_from);
             else launch_nn_red<2>(icp);
             if (fz && k + 1 >= icp->fz_from)
                 hipLaunchKernelGGL(k_reduce_solve_fz, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, K, icp->d_boxes.as<ScanBox>(), freeze_bufs(icp, true), icp->fz_prm,
@@ -3590,7 +3662,7 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
         ProfScope ps(icp, SF_PROF_REDUCE);
         hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl, freeze_bufs(icp, false));
     } else {
-        if (freeze_nn_now(icp, mode)) launch_nn_red_fz(icp, icp->shard);
+        if (freeze_nn_now(icp, mode)) launch_nn_red_fz(icp, icp->shard, icp->fz_step > icp->fz_from);
         else launch_nn_red<2>(icp, icp->shard);
         ProfScope ps(icp, SF_PROF_REDUCE);
         hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl,
@@ -3692,7 +3764,7 @@ int shard_step_p2p(sf_icp *icp, int mode, int first, const sf::P2pView &view)
     const int nb = icp->own_nblocks, B = icp->batch, K = icp->prm.num_iters;
     const bool fz_nn = freeze_nn_now(icp, mode), fz_solve = freeze_solve_now(icp, mode);
     if (mode == SF_ICP_O3D_P2P) launch_nn_red<1>(icp, true);
-    else if (fz_nn) launch_nn_red_fz(icp, true);
+    else if (fz_nn) launch_nn_red_fz(icp, true, icp->fz_step > icp->fz_from);
     else launch_nn_red<2>(icp, true);
     {
         ProfScope ps(icp, SF_PROF_REDUCE);
