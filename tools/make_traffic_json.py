@@ -49,17 +49,24 @@ try:
     avg_ns = tr[tk]["avg_ns"]
 except (OSError, KeyError, ValueError):
     pass
-fz = None
-try:   # the frozen-pair launches (k_nn_red_fz: one freeze launch + the frozen ones per alignment), averaged over all of them
-    fk = max((k for k in rd if k.startswith("k_nn_red_fz")), key=lambda k: rd[k]["TCC_EA0_RDREQ_sum"]["avg"])
-    fr, fw = rd[fk], wr[fk]
-    f_read = sum(sz * fr["TCC_EA0_RDREQ_%s" % nm]["avg"] for sz, nm in ((32, "32B_sum"), (64, "64B_sum"), (128, "128B_sum")))
-    f_write = 64 * fw["TCC_EA0_WRREQ_64B_sum"]["avg"] + 32 * max(fw["TCC_EA0_WRREQ_sum"]["avg"] - fw["TCC_EA0_WRREQ_64B_sum"]["avg"], 0.0)
-    ft = max((k for k in tr if k.startswith("k_nn_red_fz")), key=lambda k: tr[k]["launches"] * tr[k]["avg_ns"])
-    fz = {"kernel": fk.split(" grid=")[0], "traffic_bytes_per_launch_avg": f_read + f_write, "avg_launch_ns_kernel_trace": tr[ft]["avg_ns"],
-          "min_launch_ns": tr[ft]["min_ns"], "max_launch_ns": tr[ft]["max_ns"], "launches_traced": tr[ft]["launches"]}
-except (ValueError, KeyError, NameError):
-    pass
+def side_kernel(prefix_name):
+    """traffic and kernel-trace duration of another kernel of the same runs (None if it did not run)"""
+    try:
+        fk = max((k for k in rd if k.startswith(prefix_name)), key=lambda k: rd[k]["TCC_EA0_RDREQ_sum"]["avg"])
+        fr, fw = rd[fk], wr[fk]
+        f_read = sum(sz * fr["TCC_EA0_RDREQ_%s" % nm]["avg"] for sz, nm in ((32, "32B_sum"), (64, "64B_sum"), (128, "128B_sum")))
+        f_write = 64 * fw["TCC_EA0_WRREQ_64B_sum"]["avg"] + 32 * max(fw["TCC_EA0_WRREQ_sum"]["avg"] - fw["TCC_EA0_WRREQ_64B_sum"]["avg"], 0.0)
+        ft = max((k for k in tr if k.startswith(prefix_name)), key=lambda k: tr[k]["launches"] * tr[k]["avg_ns"])
+        return {"kernel": fk.split(" grid=")[0], "traffic_bytes_per_launch_avg": f_read + f_write, "avg_launch_ns_kernel_trace": tr[ft]["avg_ns"],
+                "min_launch_ns": tr[ft]["min_ns"], "max_launch_ns": tr[ft]["max_ns"], "launches_traced": tr[ft]["launches"]}
+    except (ValueError, KeyError, NameError):
+        return None
+
+
+# the frozen pairs: the launch in which scans freeze (k_nn_red_fz, full grid) and the launches after it (k_nn_red_fz_few)
+fz = {"freeze_launch": side_kernel("k_nn_red_fz<"), "frozen_launches": side_kernel("k_nn_red_fz_few")}
+if fz["freeze_launch"] is None and fz["frozen_launches"] is None:
+    fz = None
 out = {
     "kernel": key.split(" grid=")[0],
     "frozen_pairs_kernel": fz,
