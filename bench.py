@@ -224,6 +224,8 @@ def main():
             except Exception:
                 c.close()
                 raise
+            if os.environ.get("SF_COMM_TIMEOUT_S"):    # how long a collective waits for a peer before every rank is told to stop (default 20 s)
+                c.set_timeout(float(os.environ["SF_COMM_TIMEOUT_S"]))
             return c
 
         def make_rccl(lo, hi):

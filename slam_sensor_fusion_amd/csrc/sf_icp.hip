@@ -1554,29 +1554,31 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz_few(SfGrid g, S
     }
 }
 
-// fixed-order column sums of a slab with rows of STRIDE doubles, NCOL columns (NCOL <= 96), by 1024 threads:
-// thread (slice s of 8, column c of up to 128) adds rows s, s + 8, ...; the 8 slices are then added in order
-template <int STRIDE, int NCOL>
+// fixed-order column sums of a slab with rows of STRIDE doubles, NCOL columns (NCOL <= 128), by NT threads (a multiple of
+// 128): thread (slice s of NT / 128, column c of 128) adds rows s, s + NT / 128, ...; the slices are then added in order
+template <int STRIDE, int NCOL, int NT>
 __device__ __forceinline__ void reduce_columns(const double *__restrict__ part, int nrows, double *out)
 {
-    __shared__ double sl[8][128];
+    constexpr int NS = NT / 128;
+    static_assert(NT % 128 == 0 && NS >= 1 && NCOL <= 128, "slices of 128 columns");
+    __shared__ double sl[NS][128];
     const int c = threadIdx.x & 127, sidx = threadIdx.x >> 7;
     double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
     if (c < NCOL) {
         int r = sidx;
-        for (; r + 24 < nrows; r += 32) {
-            const double a0 = part[(size_t)r * STRIDE + c], a1 = part[(size_t)(r + 8) * STRIDE + c];
-            const double a2 = part[(size_t)(r + 16) * STRIDE + c], a3 = part[(size_t)(r + 24) * STRIDE + c];
+        for (; r + 3 * NS < nrows; r += 4 * NS) {
+            const double a0 = part[(size_t)r * STRIDE + c], a1 = part[(size_t)(r + NS) * STRIDE + c];
+            const double a2 = part[(size_t)(r + 2 * NS) * STRIDE + c], a3 = part[(size_t)(r + 3 * NS) * STRIDE + c];
             v0 += a0; v1 += a1; v2 += a2; v3 += a3;
         }
-        for (; r < nrows; r += 8) v0 += part[(size_t)r * STRIDE + c];
+        for (; r < nrows; r += NS) v0 += part[(size_t)r * STRIDE + c];
     }
     sl[sidx][c] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (threadIdx.x < NCOL) {
         double v = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v += sl[k][threadIdx.x];
+        for (int k = 0; k < NS; ++k) v += sl[k][threadIdx.x];
         out[threadIdx.x] = v;
     }
     __syncthreads();
@@ -1677,8 +1679,10 @@ struct FreezeBufs {
 // their moments; a freeze launch's moments and lists are folded and the freeze held or voided here.  `stride`: slab rows
 // per scan, `rows`: the rows an ordinary launch of this scan writes.  What a rank freezes is its own business (sharded: its
 // owned queries): the record it contributes is the same sum either way.
+template <int NT>
 __device__ __forceinline__ void freeze_fold(const IcpState *S, FreezeState *F, int b, const double *__restrict__ partials, int stride, int rows, const FreezeBufs &fb, double *rec)
 {
+    static_assert(NT >= FZ_NMOM && NT >= 64, "the moments are copied and contracted by the first threads");
     const int fmode = F->mode;
     __shared__ double mom[FZ_NMOM];
     __shared__ double D[12];
@@ -1686,20 +1690,20 @@ __device__ __forceinline__ void freeze_fold(const IcpState *S, FreezeState *F, i
     __shared__ uint32_t act_total;
     // frozen: only the first rows were written, by the workgroups that had a piece of the scan's active list
     const int rows_live = fmode == 2 ? (int)((F->n_active + FZ_CAP - 1) / FZ_CAP) : rows;
-    reduce_partials<NREC_PLANE>(partials + (size_t)b * stride * REC_STRIDE, rows_live, rec);
+    reduce_partials<NREC_PLANE, NT>(partials + (size_t)b * stride * REC_STRIDE, rows_live, rec);
     if (fmode == 1) {
-        reduce_columns<FZ_NMOM, FZ_NMOM>(fb.mom_part + (size_t)b * stride * FZ_NMOM, rows, mom);
+        reduce_columns<FZ_NMOM, FZ_NMOM, NT>(fb.mom_part + (size_t)b * stride * FZ_NMOM, rows, mom);
         // the rows' active lists -> one list per scan (row order, slot order inside a row): where each row's piece starts ...
-        __shared__ uint32_t pre[RBLK];
+        __shared__ uint32_t pre[NT];
         if (threadIdx.x == 0) act_worst = 0u;
         __syncthreads();
         uint32_t run = 0;
-        for (int r0 = 0; r0 < rows; r0 += RBLK) {
+        for (int r0 = 0; r0 < rows; r0 += NT) {
             const int r = r0 + (int)threadIdx.x;
             const uint32_t c = r < rows ? fb.act_cnt[(size_t)b * stride + r] : 0u;
             pre[threadIdx.x] = c;
             __syncthreads();
-            for (int off = 1; off < RBLK; off <<= 1) { // inclusive scan of the chunk
+            for (int off = 1; off < NT; off <<= 1) { // inclusive scan of the chunk
                 const uint32_t t = (int)threadIdx.x >= off ? pre[threadIdx.x - off] : 0u;
                 __syncthreads();
                 pre[threadIdx.x] += t;
@@ -1709,7 +1713,7 @@ __device__ __forceinline__ void freeze_fold(const IcpState *S, FreezeState *F, i
             if (c > (uint32_t)FZ_CAP) atomicMax(&act_worst, c);
             if (r < rows && c <= (uint32_t)FZ_CAP) // ... and the copy (a row that overflowed: the freeze does not hold, the list is not used)
                 for (uint32_t i = 0; i < c; ++i) fb.act_all[(size_t)b * stride * FZ_CAP + start + i] = (uint32_t)r * (uint32_t)(BLK * SF_WIDE_QPL) + fb.act_ids[((size_t)b * stride + r) * FZ_CAP + i];
-            run += pre[RBLK - 1];
+            run += pre[NT - 1];
             __syncthreads();
         }
         if (threadIdx.x == 0) act_total = run;
@@ -1777,7 +1781,7 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve_fz(IcpState *__restrict__
     if (S->done) return;
     FreezeState *F = fb.fz + b;
     __shared__ double rec[REC_STRIDE];
-    freeze_fold(S, F, b, partials, nblocks, nblocks, fb, rec);
+    freeze_fold<RBLK>(S, F, b, partials, nblocks, nblocks, fb, rec);
     if (threadIdx.x == 0) {
         for (int c = 0; c < NREC_PLANE; ++c) S->rec[c] = rec[c];
         double To[12];
@@ -1798,9 +1802,14 @@ __global__ void k_fz_init(FreezeState *__restrict__ fz, int batch)
     F->mode = 0; F->tries = 0; F->froze = 0; F->thawed = 0; F->n_active = 0; F->guard = 0.0f; F->launch_mode = 0; F->motion0 = 0.0;
 }
 
+// The reduce kernels of the stepping / sharded paths run on SBLK = 256 threads, one wave per SIMD: a 1024-thread workgroup at
+// 122 VGPRs (the frozen-pair fold) needs the WHOLE register file of a compute unit, and when several ranks share one device a
+// peer's k_gather_solve waves spinning for this very record sit on every unit -- measured: 4 ranks x 64 scans on one GPU never
+// got their publish kernels placed (every rank timed out in the collective).  A slab of a shard has few rows anyway.
+constexpr int SBLK = 256;
 // multi-GPU split: reduce into the exchange buffer, all-reduce outside, then solve
 template <int MODE>
-__global__ __launch_bounds__(RBLK) void k_reduce_only(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, double *__restrict__ xchg,
+__global__ __launch_bounds__(SBLK) void k_reduce_only(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, double *__restrict__ xchg,
                                                       const uint32_t *__restrict__ own_off, int qpl, FreezeBufs fb)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
@@ -1811,8 +1820,8 @@ __global__ __launch_bounds__(RBLK) void k_reduce_only(IcpState *__restrict__ st,
         return;
     }
     const int rows = own_off ? (int)((own_off[b + 1] - own_off[b] + BLK * qpl - 1) / (BLK * qpl)) : nblocks; // sharded: workgroups beyond the owned queries wrote nothing
-    if (MODE == 2 && fb.fz) freeze_fold(st + b, fb.fz + b, b, partials, nblocks, rows, fb, rec);
-    else reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, rows, rec);
+    if (MODE == 2 && fb.fz) freeze_fold<SBLK>(st + b, fb.fz + b, b, partials, nblocks, rows, fb, rec);
+    else reduce_partials<NREC, SBLK>(partials + (size_t)b * nblocks * REC_STRIDE, rows, rec);
     if (threadIdx.x < REC_STRIDE) xchg[(size_t)b * REC_STRIDE + threadIdx.x] = rec[threadIdx.x];
 }
 
@@ -1848,7 +1857,7 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
 // Per iteration two small kernels instead of three (reduce / all-reduce / solve), and no 148 bytes of scratch per lane for the
 // record.  Protocol, fences and failure behaviour as k_p2p_allreduce (sf_shard.cpp); flags are per scan (sf_p2p.hpp).
 template <int MODE>
-__global__ __launch_bounds__(RBLK) void k_reduce_publish(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, const uint32_t *__restrict__ own_off, int qpl,
+__global__ __launch_bounds__(SBLK) void k_reduce_publish(IcpState *__restrict__ st, const double *__restrict__ partials, int nblocks, const uint32_t *__restrict__ own_off, int qpl,
                                                          sf::P2pView v, FreezeBufs fb)
 {
     constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
@@ -1862,12 +1871,12 @@ __global__ __launch_bounds__(RBLK) void k_reduce_publish(IcpState *__restrict__ 
         __syncthreads();
     } else {
         const int rows = own_off ? (int)((own_off[b + 1] - own_off[b] + BLK * qpl - 1) / (BLK * qpl)) : nblocks;
-        if (MODE == 2 && fb.fz) freeze_fold(st + b, fb.fz + b, b, partials, nblocks, rows, fb, rec);
-        else reduce_partials<NREC>(partials + (size_t)b * nblocks * REC_STRIDE, rows, rec); // (both end with a barrier)
+        if (MODE == 2 && fb.fz) freeze_fold<SBLK>(st + b, fb.fz + b, b, partials, nblocks, rows, fb, rec);
+        else reduce_partials<NREC, SBLK>(partials + (size_t)b * nblocks * REC_STRIDE, rows, rec); // (both end with a barrier)
     }
     if (dead) return; // the communicator is poisoned: k_gather_solve reports it
-    if (tid < REC_STRIDE * R) {
-        const int c = tid & (REC_STRIDE - 1), r = tid / REC_STRIDE;
+    for (int i = tid; i < REC_STRIDE * R; i += SBLK) {
+        const int c = i & (REC_STRIDE - 1), r = i / REC_STRIDE;
         __hip_atomic_store(sf::p2p_slot(v.peers.region[r], par, me, R, v.max_count) + (size_t)b * REC_STRIDE + c, rec[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3660,12 +3669,12 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
     if (mode == SF_ICP_O3D_P2P) {
         launch_nn_red<1>(icp, icp->shard);
         ProfScope ps(icp, SF_PROF_REDUCE);
-        hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl, freeze_bufs(icp, false));
+        hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(SBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl, freeze_bufs(icp, false));
     } else {
         if (freeze_nn_now(icp, mode)) launch_nn_red_fz(icp, icp->shard, icp->fz_step > icp->fz_from);
         else launch_nn_red<2>(icp, icp->shard);
         ProfScope ps(icp, SF_PROF_REDUCE);
-        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(RBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl,
+        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(SBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl,
                            freeze_bufs(icp, freeze_nn_now(icp, mode)));
     }
     SF_HIP(hipGetLastError());
@@ -3768,8 +3777,8 @@ int shard_step_p2p(sf_icp *icp, int mode, int first, const sf::P2pView &view)
     else launch_nn_red<2>(icp, true);
     {
         ProfScope ps(icp, SF_PROF_REDUCE);
-        if (mode == SF_ICP_O3D_P2P) hipLaunchKernelGGL(k_reduce_publish<1>, dim3(B), dim3(RBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qpl, view, freeze_bufs(icp, false));
-        else hipLaunchKernelGGL(k_reduce_publish<2>, dim3(B), dim3(RBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qpl, view, freeze_bufs(icp, fz_nn));
+        if (mode == SF_ICP_O3D_P2P) hipLaunchKernelGGL(k_reduce_publish<1>, dim3(B), dim3(SBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qpl, view, freeze_bufs(icp, false));
+        else hipLaunchKernelGGL(k_reduce_publish<2>, dim3(B), dim3(SBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qpl, view, freeze_bufs(icp, fz_nn));
     }
     {
         ProfScope ps(icp, SF_PROF_COLLECTIVE); // the wait for the peers' records AND the solve

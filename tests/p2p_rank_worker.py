@@ -6,6 +6,7 @@ results go to <dir>/out_rank<r>.npz, failures to a non-zero exit code.
 argv: <dir> <rank> <world> <case>
   case "parity"  spanning scans: p2plane at margin 1.0 and 0.2 (stale -> resume), o3d_p2p; every alignment twice
   case "routed"  scans routed to the slabs they touch: one-slab scans alone, sub-group communicators for the rest
+  case "crowd"   hundreds of scans in flight per rank (co-residency of the ranks' small kernels on one device)
   case "peer_dies"  the last rank leaves after the first alignment; the others must get SF_ERR_COMM, not wait
   case "peer_aborts" the last rank calls sf_comm_abort instead of its second alignment
 """
@@ -71,6 +72,19 @@ def main():
                 out["%s_r%d_owned" % (name, rep)] = icp.owned_counts()
             icp.close()
         comm.status()
+    elif case == "crowd":
+        # many scans in flight: (world - 1) x scans waves of the peers' gather kernels spin on this device while this rank's
+        # publish kernel has to be placed
+        comm = comm_for(0, world - 1, 32 * len(scans))
+        comm.set_timeout(30.0)
+        icp = new_icp(8, 1.0)
+        my_slab(icp)
+        icp.set_source_batch(scans)
+        icp.set_initial_batch(inits)
+        res = icp.align_sharded("p2plane", comm)
+        for k, v in pack(res).items():
+            out["crowd_" + k] = v
+        icp.close()
     elif case == "routed":
         comms = {}
 

@@ -93,6 +93,26 @@ def test_c_side_sharded_loop_with_p2p_ranks_on_one_gpu(api, ctx, synth, small_wo
                 assert (owned.max(0) < scans.shape[1]).all()                    # and no rank walks a whole scan
 
 
+def test_many_scans_in_flight_with_four_ranks_on_one_gpu(api, ctx, synth, small_world, tmp_path):
+    """320 scans per rank: three peers' gather kernels (one wave per scan, spinning until every rank has published) put a
+    wave on every compute unit of the device while this rank's publish kernel still has to be placed.  With the publish
+    kernel on 1024 threads at 122 VGPRs -- a whole unit's register file per workgroup -- it never was (every rank timed out;
+    found with bench.py's default batch on 4 ranks); it runs on 256 threads."""
+    ds = small_world["map"]
+    world, B = 4, 320
+    scans = np.stack([synth.make_scan(ds, 1500, scan_id=100 + s)[0] for s in range(B)])
+    inits = np.stack([np.eye(4)] * B)
+    outs = run_ranks(tmp_path, world, "crowd", ds, scans, inits, timeout=200)
+    assert len(outs) == world
+    for r in range(1, world):
+        assert np.array_equal(outs[r]["crowd_T"], outs[0]["crowd_T"])
+    assert (outs[0]["crowd_iterations"] == 8).all() and (outs[0]["crowd_flags"] == 0).all()
+    ref = unsharded(api, ctx, ds, scans[:4], inits[:4], "p2plane", 8)
+    for b in range(4):
+        dt, dr = synth.pose_error(outs[0]["crowd_T"][b], ref[b]["T64"])
+        assert dt < 1e-9 and dr < 1e-10 and outs[0]["crowd_n_corr"][b] == ref[b]["n_corr"]
+
+
 def test_routed_subgroups_over_p2p(api, ctx, orc, synth, tmp_path):
     """Four slabs of a 20 m map; scans inside one slab (no collective), straddling two and three slabs (communicators
     of just those ranks) and over the whole map (all four)."""
