@@ -1375,33 +1375,38 @@ __device__ __forceinline__ void nn_red_fz_row(const SfGrid &g, const SfWindow &w
     LanePair P[Q];
     if (fmode == 2) {
         // the scan's active queries, FZ_CAP per workgroup from the scan's list (the reduce kernel wrote it, in row and slot
-        // order), taken by wave 0 in Q rounds; workgroups beyond the list leave at once, the reduce kernel adds only the rows
+        // order); workgroups beyond the list leave at once, the reduce kernel adds only the rows
         // that were written.  (Measured as a full grid, 31.3 us per launch: four waves side by side with 64 each 33.8, a
         // fixed grid of resident workgroups walking the rows with the per-scan state in LDS 32.1 -- and 13 us with this path
         // returning at once: the dispatch of 25 000 workgroups that find their scan frozen.  Hence k_nn_red_fz_few, 19 us.)
-        if (wv != 0) return;
+        // Waves 0 .. Q-1 take 64 of the piece's queries each, side by side (one round trip chain instead of Q in a row); the
+        // whole workgroup meets at the barrier and the waves' records are added in wave order.
         const int64_t total = fz[b].n_active, first = (int64_t)bx * FZ_CAP;
         if (first >= total) return;
-        const uint32_t cnt = (uint32_t)min<int64_t>(total - first, FZ_CAP);
-        const uint32_t *list = act_all + (size_t)b * nblocks * FZ_CAP + (size_t)first;
-#pragma unroll
-        for (int u = 0; u < Q; ++u) {
-            const uint32_t i = (uint32_t)(u * 64 + lane);
+        __shared__ double fstage[Q][32];
+        if (wv < Q) {
+            const uint32_t cnt = (uint32_t)min<int64_t>(total - first, FZ_CAP);
+            const uint32_t *list = act_all + (size_t)b * nblocks * FZ_CAP + (size_t)first;
+            const uint32_t i = (uint32_t)(wv * 64 + lane);
             const int slot = i < cnt ? (int)list[i] : n_live; // n_live: no query
-            P[u] = nn_pair<MODE, false, SHARD>(g, w, X0x, X0y, X0z, n, b, S, thr, xlo, xhi, own_off, qcache, cache_n, slot, n_live, &nn_ws[0], stats);
-        }
+            const LanePair A1 = nn_pair<MODE, false, SHARD>(g, w, X0x, X0y, X0z, n, b, S, thr, xlo, xhi, own_off, qcache, cache_n, slot, n_live, &nn_ws[wv], stats);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            double v[16];
+            for (int h = 0; h < 2; ++h) {
+                double v[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = 0.0;
-#pragma unroll
-            for (int u = 0; u < Q; ++u) {
-                const PairTerms t = pair_terms<MODE>(P[u]);
+                for (int k = 0; k < 16; ++k) v[k] = 0.0;
+                const PairTerms t = pair_terms<MODE>(A1);
                 add_half<MODE>(t, h, v);
+                const double t0 = wave_reduce_16(v);
+                if ((lane & 3) == 0) fstage[wv][16 * h + (lane >> 2)] = t0;
             }
-            const double t0 = wave_reduce_16(v);
-            if ((lane & 3) == 0 && 16 * h + (lane >> 2) < NREC) dst[16 * h + (lane >> 2)] = t0;
+        }
+        __syncthreads();
+        if (threadIdx.x < NREC) {
+            double v = fstage[0][threadIdx.x];
+#pragma unroll
+            for (int u = 1; u < Q; ++u) v += fstage[u][threadIdx.x];
+            dst[threadIdx.x] = v;
         }
         return;
     }
@@ -1470,7 +1475,17 @@ __device__ __forceinline__ void nn_red_fz_row(const SfGrid &g, const SfWindow &w
         }
         if (threadIdx.x == 0) act_cnt[row] = total; // beyond FZ_CAP: the freeze does not hold (k_reduce_solve_fz)
     }
-    // the ordinary record: every pair (mode 0) / the active pairs (freeze launch)
+    // the ordinary record: every pair (mode 0) / the active pairs (freeze launch: three waves in four have none -- their
+    // record is zero without forming and reducing it)
+    bool wave_has_pairs = true;
+    if (fmode == 1) {
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < Q; ++u) any = any || (P[u].ok && active[u]);
+        wave_has_pairs = __ballot(any) != 0ull;
+        if (!wave_has_pairs && lane < 32) stage[wv][lane] = 0.0;
+    }
+    if (wave_has_pairs)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         double v[16];
@@ -1543,9 +1558,11 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz_few(SfGrid g, S
     if (A.st[b].done) return;
     const int fmode = A.fz[b].mode;
     if (fmode == 2) {
-        if (threadIdx.x >= 64) return; // wave 0 takes the pieces
         const int64_t total = A.fz[b].n_active;
-        for (int bx = r; (int64_t)bx * FZ_CAP < total; bx += FZ_FEW) nn_red_fz_row<Q, SHARD>(g, w, A, b, bx, 2);
+        for (int bx = r; (int64_t)bx * FZ_CAP < total; bx += FZ_FEW) {
+            nn_red_fz_row<Q, SHARD>(g, w, A, b, bx, 2);
+            __syncthreads();
+        }
         return;
     }
     for (int bx = r; bx < A.nblocks; bx += FZ_FEW) {
