@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve(IcpState *__restrict__ st
 //   [74,80) x_d x_e   [80,83) x_d   [83,92) p_a x_d (83 + 3 a + d)   [92,95) p_a   95 |p|^2
 constexpr int FZ_NMOM = 96;
 constexpr int FZ_CAP = 128;  // active queries one slab row can list (of its 256 * Q)
-constexpr int64_t FREEZE_AUTO_MIN_QUERIES = 4000000; // sf_icp_set_freeze(1): batches from this many queries on
+constexpr int64_t FREEZE_AUTO_MIN_QUERIES = 1000000; // sf_icp_set_freeze(1): batches from this many queries on (measured break-even: 0.8 M)
 struct FreezeState {
     int mode;         // 0: every query evaluated launch by launch, 1: the next launch is a freeze launch, 2: frozen
     int tries;        // freeze launches that did not hold (a row's list overflowed) + thaws
@@ -2846,8 +2846,9 @@ void launch_nn_red(sf_icp *icp, bool sharded = false)
 // owned queries (what it contributes to the all-reduced record is the same sum either way)
 bool freeze_on(const sf_icp *icp, int mode)
 {
-    // a frozen launch costs the latency of one search (31 us measured) + the solve, whatever the batch: below ~4 M queries per
-    // launch a verifying launch is cheaper than that (one 200 k-point scan: 0.39 ms per alignment without, 0.48 ms with)
+    // a frozen launch costs one wave's chain of round trips (16 us) + the solve, whatever the batch: for a small batch a verifying
+    // launch is cheaper than that (200 k-point scans, ms per alignment without / with: one scan 0.39 / 0.45, four 0.77 / 0.75,
+    // eight 1.07 / 0.97, sixteen 1.68 / 1.42)
     const int64_t queries = icp->shard ? icp->own_total : icp->n * icp->batch;
     const bool wanted = icp->freeze == 2 || (icp->freeze == 1 && queries >= FREEZE_AUTO_MIN_QUERIES);
     return mode == SF_ICP_P2PLANE && wanted && icp->reuse && icp->qpl == SF_WIDE_QPL && icp->map->window.kind == 0 && icp->prm.num_iters > icp->fz_from + 1 &&
