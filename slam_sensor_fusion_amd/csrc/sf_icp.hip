@@ -2811,11 +2811,13 @@ sf_icp::GraphKey graph_key_now(const sf_icp *icp, int mode)
 
 float o3d_thr(const sf_icp *icp) { return (float)((double)icp->prm.max_corr * (double)icp->prm.max_corr); }
 
+// one_per_lane: a wide scan's launch with ONE query per lane (rows of 256 queries: icp->nblocks of them) -- the launches in
+// which nearly every query searches, where the second query per lane only costs registers (enqueue_align)
 template <int MODE>
-void launch_nn_red(sf_icp *icp, bool sharded = false)
+void launch_nn_red(sf_icp *icp, bool sharded = false, bool one_per_lane = false)
 {
     sf_map *m = icp->map;
-    const int nb = sharded ? icp->own_nblocks : icp->nblocks_nn;
+    const int nb = sharded ? icp->own_nblocks : (one_per_lane ? icp->nblocks : icp->nblocks_nn);
     const dim3 grid((unsigned)((nb + 7) & ~7), (unsigned)icp->batch), blk(BLK); // see the XCD mapping in k_nn_red
     const float *x = src(icp, 0), *y = src(icp, 1), *z = src(icp, 2);
     const IcpState *st = icp->state.as<IcpState>();
@@ -2831,7 +2833,7 @@ void launch_nn_red(sf_icp *icp, bool sharded = false)
                        icp->own_off.as<uint32_t>(), icp->reuse ? icp->qcache.as<float4>() : nullptr, icp->cache_n, stats)
 #define SF_LAUNCH_NNRED(W, S)                                  \
     do {                                                       \
-        if (icp->qpl == 1) SF_LAUNCH_NNRED_Q(W, S, 1);         \
+        if (icp->qpl == 1 || one_per_lane) SF_LAUNCH_NNRED_Q(W, S, 1); \
         else SF_LAUNCH_NNRED_Q(W, S, SF_WIDE_QPL);             \
     } while (0)
     if (win && sharded) SF_LAUNCH_NNRED(true, true);
@@ -2977,10 +2979,16 @@ int enqueue_align(sf_icp *icp, int mode)
         if (fz) { // (buffers: freeze_alloc, before any capture)
             hipLaunchKernelGGL(k_fz_init, dim3(nblk(B, 64)), dim3(64), 0, s, icp->fz_state.as<FreezeState>(), B);
         }
+        // wide scans: the first launches -- nearly every query searches -- run one query per lane (fewer registers: measured
+        // 929, 804, 508, 414 against 954, 836, 539, 439 us); from the launch in which waves start to certify whole, two
+        const bool wide = icp->qpl > 1 && !icp->shard;
         for (int k = 0; k < K; ++k) {
+            const bool q1 = wide && k < VERIFY_FROM_SEARCH; // (the same schedule with the reuse off: it is part of the summation order, and reuse on == off bit for bit)
             if (fz && k >= icp->fz_from) launch_nn_red_fz(icp, false, k > icp->fz_from);
-            else launch_nn_red<2>(icp);
-            if (fz && k + 1 >= icp->fz_from)
+            else launch_nn_red<2>(icp, false, q1);
+            if (q1)
+                hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks, n, k, K, icp->d_boxes.as<ScanBox>());
+            else if (fz && k + 1 >= icp->fz_from)
                 hipLaunchKernelGGL(k_reduce_solve_fz, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, K, icp->d_boxes.as<ScanBox>(), freeze_bufs(icp, true), icp->fz_prm,
                                    (int)(k + 2 < K));
             else

@@ -18,18 +18,29 @@ kname = "k_ref_nn" if mode == "ref_cpp" else "k_nn_red"
 rd = json.load(open(prefix + "_rdsz_pmc.json"))
 wr = json.load(open(prefix + "_wrsz_pmc.json"))
 mine = lambda k: k.startswith(kname) and not k.startswith("k_nn_red_fz")   # (k_nn_red_fz: the launches after the freeze, reported apart)
-key = max((k for k in rd if mine(k)), key=lambda k: rd[k]["TCC_EA0_RDREQ_sum"]["avg"])   # the batched launches
-r, w = rd[key], wr[key]
-n32, n64, n128, nall = (r["TCC_EA0_RDREQ_%s" % s]["avg"] for s in ("32B_sum", "64B_sum", "128B_sum", "sum"))
+top = max(rd[k]["TCC_EA0_RDREQ_sum"]["avg"] for k in rd if mine(k))
+keys = sorted(k for k in rd if mine(k) and rd[k]["TCC_EA0_RDREQ_sum"]["avg"] >= 0.1 * top)   # the batched launches of every variant of the kernel
+key = keys[0]                                                                                   # (one or two queries per lane: same kernel, two instantiations)
+
+
+def wavg(tab, counter):
+    """average per launch over all variants, weighted by their launches"""
+    n = sum(tab[k][counter]["dispatches"] for k in keys)
+    return sum(tab[k][counter]["avg"] * tab[k][counter]["dispatches"] for k in keys) / n
+
+
+n32, n64, n128, nall = (wavg(rd, "TCC_EA0_RDREQ_%s" % s) for s in ("32B_sum", "64B_sum", "128B_sum", "sum"))
 other = nall - n32 - n64 - n128
 read_b = 32 * n32 + 64 * n64 + 128 * n128 + 64 * max(other, 0.0)
-w64, wall = w["TCC_EA0_WRREQ_64B_sum"]["avg"], w["TCC_EA0_WRREQ_sum"]["avg"]
+w64, wall = wavg(wr, "TCC_EA0_WRREQ_64B_sum"), wavg(wr, "TCC_EA0_WRREQ_sum")
 write_b = 64 * w64 + 32 * max(wall - w64, 0.0)
 q = 200000 * batch
 valu = None
 try:
-    sq = json.load(open(prefix + "_sq_pmc.json"))[key]
-    sq2 = json.load(open(prefix + "_sq2_pmc.json"))[key]
+    sq_all = json.load(open(prefix + "_sq_pmc.json"))
+    sq2_all = json.load(open(prefix + "_sq2_pmc.json"))
+    sq = {c: {"avg": wavg(sq_all, c)} for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS")}
+    sq2 = {c: {"avg": wavg(sq2_all, c)} for c in ("GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU")}
     waves = sq["SQ_WAVES"]["avg"]
     cycles = sq2["GRBM_GUI_ACTIVE"]["avg"] / 8.0                       # rocprofv3 sums the 8 XCDs
     n_simd = 1024
@@ -45,8 +56,8 @@ except (OSError, KeyError):
 avg_ns = None
 try:
     tr = json.load(open(prefix + "_final_kernel_trace_by_grid.json"))
-    tk = max((k for k in tr if mine(k)), key=lambda k: tr[k]["launches"] * tr[k]["avg_ns"])
-    avg_ns = tr[tk]["avg_ns"]
+    tks = [k for k in tr if mine(k) and tr[k]["avg_ns"] * tr[k]["launches"] >= 0.02 * max(tr[j]["avg_ns"] * tr[j]["launches"] for j in tr if mine(j))]
+    avg_ns = sum(tr[k]["avg_ns"] * tr[k]["launches"] for k in tks) / sum(tr[k]["launches"] for k in tks)
 except (OSError, KeyError, ValueError):
     pass
 def side_kernel(prefix_name):
@@ -68,7 +79,8 @@ fz = {"freeze_launch": side_kernel("k_nn_red_fz<"), "frozen_launches": side_kern
 if fz["freeze_launch"] is None and fz["frozen_launches"] is None:
     fz = None
 out = {
-    "kernel": key.split(" grid=")[0],
+    "kernel": " + ".join(k.split(" grid=")[0] for k in keys),
+    "launches_profiled": {k.split(" grid=")[0]: rd[k]["TCC_EA0_RDREQ_sum"]["dispatches"] for k in keys},
     "frozen_pairs_kernel": fz,
     "avg_launch_ns_kernel_trace": avg_ns,
     "frac_of_hbm_peak_kernel_trace": ((read_b + write_b) / (avg_ns * 1e-9) / 8e12) if avg_ns else None,
