@@ -6,6 +6,7 @@ results go to <dir>/out_rank<r>.npz, failures to a non-zero exit code.
 argv: <dir> <rank> <world> <case>
   case "parity"  spanning scans: p2plane at margin 1.0 and 0.2 (stale -> resume), o3d_p2p; every alignment twice
   case "routed"  scans routed to the slabs they touch: one-slab scans alone, sub-group communicators for the rest
+  case "frozen"  wide scans, frozen pairs forced on, over the P2P collective
   case "crowd"   hundreds of scans in flight per rank (co-residency of the ranks' small kernels on one device)
   case "peer_dies"  the last rank leaves after the first alignment; the others must get SF_ERR_COMM, not wait
   case "peer_aborts" the last rank calls sf_comm_abort instead of its second alignment
@@ -72,6 +73,23 @@ def main():
                 out["%s_r%d_owned" % (name, rep)] = icp.owned_counts()
             icp.close()
         comm.status()
+    elif case == "frozen":
+        # wide scans (two queries per lane) with the frozen pairs forced on: every rank freezes its own owned queries, the
+        # records still meet in the same collective
+        comm = comm_for(0, world - 1, 32 * len(scans))
+        icp = new_icp(20, 1.0)
+        icp.set_freeze(True)
+        my_slab(icp)
+        icp.set_source_batch(scans)
+        icp.set_initial_batch(inits)
+        for rep in range(2):
+            res = icp.align_sharded("p2plane", comm)
+            for k, v in pack(res).items():
+                out["frozen_r%d_%s" % (rep, k)] = v
+        st = icp.freeze_stats()
+        out["frozen_froze"] = np.array(st["froze"])
+        out["frozen_at_end"] = np.array(st["frozen_at_end"])
+        icp.close()
     elif case == "crowd":
         # many scans in flight: (world - 1) x scans waves of the peers' gather kernels spin on this device while this rank's
         # publish kernel has to be placed

@@ -93,6 +93,34 @@ def test_c_side_sharded_loop_with_p2p_ranks_on_one_gpu(api, ctx, synth, small_wo
                 assert (owned.max(0) < scans.shape[1]).all()                    # and no rank walks a whole scan
 
 
+def test_ranks_freeze_their_own_queries_over_p2p(api, ctx, orc, synth, tmp_path):
+    """Two processes, wide scans (140 k points: two queries per lane), sf_icp_set_freeze(always): each rank's reduce kernel folds
+    ITS frozen pairs' moments into the record it publishes, the gather kernel keeps the freeze state; result == the
+    unsharded launch-by-launch evaluation (1e-9), bitwise equal across ranks and runs, and every rank did freeze."""
+    world = 2
+    raw = synth.make_map(400_000)
+    ds = orc.voxel_pcl(raw, 0.1)[0]
+    scans = np.stack([synth.make_scan(ds, 140_000, scan_id=60 + k)[0] for k in range(2)])
+    inits = np.stack([np.eye(4), synth.make_T((0.03, -0.02, 0.01), (0.1, 0.0, 0.2))])
+    outs = run_ranks(tmp_path, world, "frozen", ds, scans, inits)
+    assert len(outs) == world
+    mp = api.Map(ctx, api.Cloud(ctx, ds), CELL)
+    mp.estimate_normals(NORMAL_RADIUS)
+    icp = api.Icp(ctx, MAX_DIST, 20, 0.05, 1e-5)
+    icp.set_target(mp)
+    icp.set_freeze(False)
+    icp.set_source_batch(scans)
+    icp.set_initial_batch(inits)
+    ref = icp.align_batch("p2plane")
+    for r in range(world):
+        assert int(outs[r]["frozen_froze"]) >= 2 and int(outs[r]["frozen_at_end"]) == 2, r
+        assert np.array_equal(outs[r]["frozen_r0_T"], outs[0]["frozen_r0_T"]) and np.array_equal(outs[r]["frozen_r1_T"], outs[0]["frozen_r0_T"])
+    for b in range(2):
+        assert outs[0]["frozen_r0_iterations"][b] == ref[b]["iterations"] == 20 and outs[0]["frozen_r0_n_corr"][b] == ref[b]["n_corr"]
+        dt, dr = synth.pose_error(outs[0]["frozen_r0_T"][b], ref[b]["T64"])
+        assert dt < 1e-9 and dr < 1e-10, (b, dt, dr)
+
+
 def test_many_scans_in_flight_with_four_ranks_on_one_gpu(api, ctx, synth, small_world, tmp_path):
     """320 scans per rank: three peers' gather kernels (one wave per scan, spinning until every rank has published) put a
     wave on every compute unit of the device while this rank's publish kernel still has to be placed.  With the publish
