@@ -712,7 +712,9 @@ __device__ __forceinline__ PairTerms pair_terms(const LanePair &P)
     return t;
 }
 
-// the 32 record slots of one pair, half h (0: slots 0..15, 1: slots 16..31), added to v
+// the 32 record slots of one pair, half h (0: slots 0..15, 1: slots 16..31), added to v.  The products go in as fused
+// multiply-adds (float64 accumulation of this library's own sums -- no reference arithmetic to mirror here, and the vector
+// issue slots are what the kernel runs out of: one instruction per term instead of two)
 template <int MODE>
 __device__ __forceinline__ void add_half(const PairTerms &t, int h, double (&v)[16])
 {
@@ -721,29 +723,29 @@ __device__ __forceinline__ void add_half(const PairTerms &t, int h, double (&v)[
             v[0] += t.wgt;
             v[1] += t.ux; v[2] += t.uy; v[3] += t.uz;
             v[4] += t.tx; v[5] += t.ty; v[6] += t.tz;
-            v[7] += t.ux * t.tx; v[8] += t.ux * t.ty; v[9] += t.ux * t.tz;
-            v[10] += t.uy * t.tx; v[11] += t.uy * t.ty; v[12] += t.uy * t.tz;
-            v[13] += t.uz * t.tx; v[14] += t.uz * t.ty; v[15] += t.uz * t.tz;
+            v[7] = fma(t.ux, t.tx, v[7]); v[8] = fma(t.ux, t.ty, v[8]); v[9] = fma(t.ux, t.tz, v[9]);
+            v[10] = fma(t.uy, t.tx, v[10]); v[11] = fma(t.uy, t.ty, v[11]); v[12] = fma(t.uy, t.tz, v[12]);
+            v[13] = fma(t.uz, t.tx, v[13]); v[14] = fma(t.uz, t.ty, v[14]); v[15] = fma(t.uz, t.tz, v[15]);
         } else {
             v[0] += t.d2;
         }
     } else {
         // record[0..15] = n, sum r^2, JtJ (0,0) (0,1) .. (0,5) (1,1) .. (1,5) (2,2) (2,3) (2,4)
         // record[16..31] = JtJ (2,5) (3,3) .. (5,5), Jtr[6], sum d2, 0, 0
-        if (h == 0) { v[0] += t.wgt; v[1] += t.r * t.r; }
+        if (h == 0) { v[0] += t.wgt; v[1] = fma(t.r, t.r, v[1]); }
         int k = 2;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
 #pragma unroll
             for (int c = a; c < 6; ++c) {
-                if (h == 0 && k < 16) v[k] += t.J[a] * t.J[c];
-                if (h == 1 && k >= 16) v[k - 16] += t.J[a] * t.J[c];
+                if (h == 0 && k < 16) v[k] = fma(t.J[a], t.J[c], v[k]);
+                if (h == 1 && k >= 16) v[k - 16] = fma(t.J[a], t.J[c], v[k - 16]);
                 ++k;
             }
         }
         if (h == 1) {
 #pragma unroll
-            for (int a = 0; a < 6; ++a) v[7 + a] += t.J[a] * t.r;
+            for (int a = 0; a < 6; ++a) v[7 + a] = fma(t.J[a], t.r, v[7 + a]);
             v[13] += t.d2;
         }
     }
@@ -1270,27 +1272,28 @@ __device__ __forceinline__ MomIn mom_in(const LanePair &P, bool take)
     t.c = t.n[0] * t.p[0] + t.n[1] * t.p[1] + t.n[2] * t.p[2];
     return t;
 }
+// acc + moment I of the pair, the last product fused into the addition
 template <int I>
-__device__ __forceinline__ double mom_term(const MomIn &t)
+__device__ __forceinline__ double mom_fma(const MomIn &t, double acc)
 {
-    if constexpr (I < 36) return (t.n[k6a(I / 6)] * t.n[k6b(I / 6)]) * (t.x[k6a(I % 6)] * t.x[k6b(I % 6)]);
-    else if constexpr (I < 54) return (t.n[k6a((I - 36) / 3)] * t.n[k6b((I - 36) / 3)]) * t.x[(I - 36) % 3];
-    else if constexpr (I < 60) return t.n[k6a(I - 54)] * t.n[k6b(I - 54)];
-    else if constexpr (I < 69) return (t.c * t.n[(I - 60) / 3]) * t.x[(I - 60) % 3];
-    else if constexpr (I < 72) return t.c * t.n[I - 69];
-    else if constexpr (I == 72) return t.c * t.c;
-    else if constexpr (I == 73) return t.w;
-    else if constexpr (I < 80) return t.x[k6a(I - 74)] * t.x[k6b(I - 74)];
-    else if constexpr (I < 83) return t.x[I - 80];
-    else if constexpr (I < 92) return t.p[(I - 83) / 3] * t.x[(I - 83) % 3];
-    else if constexpr (I < 95) return t.p[I - 92];
-    else return t.p[0] * t.p[0] + t.p[1] * t.p[1] + t.p[2] * t.p[2];
+    if constexpr (I < 36) return fma(t.n[k6a(I / 6)] * t.n[k6b(I / 6)], t.x[k6a(I % 6)] * t.x[k6b(I % 6)], acc);
+    else if constexpr (I < 54) return fma(t.n[k6a((I - 36) / 3)] * t.n[k6b((I - 36) / 3)], t.x[(I - 36) % 3], acc);
+    else if constexpr (I < 60) return fma(t.n[k6a(I - 54)], t.n[k6b(I - 54)], acc);
+    else if constexpr (I < 69) return fma(t.c * t.n[(I - 60) / 3], t.x[(I - 60) % 3], acc);
+    else if constexpr (I < 72) return fma(t.c, t.n[I - 69], acc);
+    else if constexpr (I == 72) return fma(t.c, t.c, acc);
+    else if constexpr (I == 73) return acc + t.w;
+    else if constexpr (I < 80) return fma(t.x[k6a(I - 74)], t.x[k6b(I - 74)], acc);
+    else if constexpr (I < 83) return acc + t.x[I - 80];
+    else if constexpr (I < 92) return fma(t.p[(I - 83) / 3], t.x[(I - 83) % 3], acc);
+    else if constexpr (I < 95) return acc + t.p[I - 92];
+    else return fma(t.p[0], t.p[0], fma(t.p[1], t.p[1], fma(t.p[2], t.p[2], acc)));
 }
 template <int H, int K = 0>
 __device__ __forceinline__ void mom_add16(const MomIn &t, double (&v)[16])
 {
     if constexpr (K < 16) {
-        v[K] += mom_term<16 * H + K>(t);
+        v[K] = mom_fma<16 * H + K>(t, v[K]);
         mom_add16<H, K + 1>(t, v);
     }
 }
