@@ -512,7 +512,14 @@ def main():
             searching = sq / max(owned, 1) > 0.5
             map_b = len(mp) * (32 if args.mode == "p2plane" else 16) + 4.0 * np.prod(mp.cell_size()[1])
             comp = np.where(searching, owned * (12.0 + (cache_b if not args.no_nn_reuse else 0)) + map_b, owned * (12.0 + cache_b))
+            # frozen pairs (a rank freezes its own owned queries): from the launch after the freeze launch only the active queries are touched
+            fzs = base.freeze_stats() if args.mode == "p2plane" else {"froze": 0, "frozen_at_end": 0, "failed": 0, "thawed": 0, "active_queries": 0}
+            streamed = len(ms)
+            if fzs["froze"] > 0 and fzs["frozen_at_end"] == len(gids) and fzs["failed"] == 0 and fzs["thawed"] == 0 and len(ms) > 6:
+                streamed = 6
+                comp[streamed:] = fzs["active_queries"] * (12.0 + cache_b)
             mine_stat.update({
+                "frozen_scans": int(fzs["frozen_at_end"]), "active_queries": int(fzs["active_queries"]), "launches_streaming_the_owned_queries": int(streamed),
                 "group": [int(a_), int(e_)], "group_scans": len(gids), "owned_queries_per_launch": owned,
                 "nn_us_per_launch": [round(float(v) * 1e3, 1) for v in ms], "nn_us_mean": float(ms.mean() * 1e3),
                 "queries_searching_frac_per_launch": [round(float(v) / max(owned, 1), 4) for v in sq],
@@ -521,8 +528,8 @@ def main():
                 "collective_us_max": float(ph["collective"].max() * 1e3) if len(ph["collective"]) else None,
                 "solve_us_mean": float(ph["solve"].mean() * 1e3) if len(ph["solve"]) else None,
                 "shard_build_ms_mean": float(ph["shard_build"].mean()) if len(ph["shard_build"]) else None,
-                "compulsory_bytes_per_launch": float(comp.mean()),
-                "compulsory_gbs": float(comp.mean() / max(ms.mean() * 1e-3, 1e-12) / 1e9),
+                "compulsory_bytes_per_launch": float(comp[:streamed].mean()),
+                "compulsory_gbs": float(comp[:streamed].mean() / max(ms[:streamed].mean() * 1e-3, 1e-12) / 1e9),   # (over the launches that stream the owned queries)
             })
         for b_ in bases:
             b_.profile_enable(False)
@@ -532,7 +539,7 @@ def main():
                 v = [st[key] for st in all_stats if st.get(key) is not None]
                 return {"min": min(v), "max": max(v), "mean": float(np.mean(v))} if v else None
             rank_stats = {k: mm(k) for k in ("step_ms", "map_points", "scans", "owned_queries_per_launch", "nn_us_mean", "reduce_us_mean", "collective_us_mean",
-                                             "collective_us_max", "solve_us_mean", "shard_build_ms_mean", "resumes")}
+                                             "collective_us_max", "solve_us_mean", "shard_build_ms_mean", "resumes", "frozen_scans", "active_queries")}
             rank_stats["per_rank"] = all_stats
             rank_stats["note"] = ("HIP events on each rank's stream around every phase of the sharded loop of its largest group, 2 profiled steps after the timed "
                                   "region; collective_us includes waiting for the slowest peer; nn_us_per_launch / queries_searching_frac_per_launch: the k_nn_red "
@@ -542,7 +549,8 @@ def main():
                 roof_dist = {"bound": "hbm", "achieved": gbs["mean"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs["mean"] / HBM_PEAK_GBS,
                              "frac_min_rank": gbs["min"] / HBM_PEAK_GBS, "frac_max_rank": gbs["max"] / HBM_PEAK_GBS, "traffic": None,
                              "achieved_from": "compulsory-traffic model per rank (owned queries x (12 B + neighbour cache) + the rank's map lines and cell table once per "
-                                              "searching launch) / that rank's mean k_nn_red launch time; mean over ranks",
+                                              "searching launch) / that rank's mean k_nn_red launch time over the launches that stream its owned queries "
+                                              "(ranks.launches_streaming_the_owned_queries: with the frozen pairs the first six); mean over ranks",
                              "kernel": "k_nn_red<SHARD>", "avg_launch_ms": mm("nn_us_mean")["mean"] * 1e-3,
                              "queries_per_launch": mm("owned_queries_per_launch")}
 
@@ -878,7 +886,8 @@ def main():
                                                                                      ("" if (args.no_freeze or args.mode != "p2plane") else
                                                                                       "; once a scan's pairs are certified to stay, their sums come from 96 moments (float64, equal to rounding)")))),
                    "mode": args.mode, "scans_in_flight": B, "scans_in_flight_per_gpu": B // world if args.scaling == "weak" else B, "cell_m": args.cell,
-                   "max_corr_dist_m": max_dist, "nn_reuse": not args.no_nn_reuse, "frozen_pairs": bool(prof is not None and prof["fz"]["froze"] > 0), "scan_kind": args.scan_kind,
+                   "max_corr_dist_m": max_dist, "nn_reuse": not args.no_nn_reuse, "frozen_pairs": bool((prof is not None and prof["fz"]["froze"] > 0) or (rank_stats is not None and (rank_stats.get("frozen_scans") or {}).get("max", 0) > 0)),
+                   "scan_kind": args.scan_kind,
                    "parallelism": ("map sharded into %d x-slabs (+halo); %s; collective: %s"
                                    % (world, "every scan spans every slab: each rank owns 1/%d of every scan's queries, all-reduce of the normal-equation records once per ICP iteration" % world
                                       if args.scan_kind == "whole" else "scans routed to the slabs they touch, one-slab scans registered by one rank without a collective", comm_kind))
