@@ -2820,7 +2820,7 @@ template <int MODE>
 void launch_nn_red(sf_icp *icp, bool sharded = false, bool one_per_lane = false)
 {
     sf_map *m = icp->map;
-    const int nb = sharded ? icp->own_nblocks : (one_per_lane ? icp->nblocks : icp->nblocks_nn);
+    const int nb = sharded ? (one_per_lane ? icp->own_nblocks * icp->qpl : icp->own_nblocks) : (one_per_lane ? icp->nblocks : icp->nblocks_nn);
     const dim3 grid((unsigned)((nb + 7) & ~7), (unsigned)icp->batch), blk(BLK); // see the XCD mapping in k_nn_red
     const float *x = src(icp, 0), *y = src(icp, 1), *z = src(icp, 2);
     const IcpState *st = icp->state.as<IcpState>();
@@ -3693,7 +3693,10 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
     if (first) SF_TRY(freeze_start_pass(icp, mode));
     double *x = reinterpret_cast<double *>(sf_icp_exchange_ptr(icp, nullptr));
     hipStream_t s = icp->ctx->stream;
-    const int nb = icp->shard ? icp->own_nblocks : icp->nblocks_nn;
+    // wide scans: the first launches of a pass with one query per lane, as enqueue_align (rows of 256: twice as many)
+    const bool q1 = mode == SF_ICP_P2PLANE && icp->qpl > 1 && icp->fz_step < VERIFY_FROM_SEARCH;
+    const int nb = icp->shard ? (q1 ? icp->own_nblocks * icp->qpl : icp->own_nblocks) : (q1 ? icp->nblocks : icp->nblocks_nn);
+    const int qpl_now = q1 ? 1 : icp->qpl;
     const uint32_t *off = icp->shard ? icp->own_off.as<uint32_t>() : nullptr;
     if (mode == SF_ICP_O3D_P2P) {
         launch_nn_red<1>(icp, icp->shard);
@@ -3701,9 +3704,9 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
         hipLaunchKernelGGL(k_reduce_only<1>, dim3(icp->batch), dim3(SBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl, freeze_bufs(icp, false));
     } else {
         if (freeze_nn_now(icp, mode)) launch_nn_red_fz(icp, icp->shard, icp->fz_step > icp->fz_from);
-        else launch_nn_red<2>(icp, icp->shard);
+        else launch_nn_red<2>(icp, icp->shard, q1);
         ProfScope ps(icp, SF_PROF_REDUCE);
-        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(SBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, icp->qpl,
+        hipLaunchKernelGGL(k_reduce_only<2>, dim3(icp->batch), dim3(SBLK), 0, s, icp->state.as<IcpState>(), icp->partials.as<double>(), nb, x, off, qpl_now,
                            freeze_bufs(icp, freeze_nn_now(icp, mode)));
     }
     SF_HIP(hipGetLastError());
@@ -3799,15 +3802,16 @@ int shard_step_p2p(sf_icp *icp, int mode, int first, const sf::P2pView &view)
     if (first) SF_TRY(freeze_start_pass(icp, mode));
     hipStream_t s = icp->ctx->stream;
     IcpState *st = icp->state.as<IcpState>();
-    const int nb = icp->own_nblocks, B = icp->batch, K = icp->prm.num_iters;
+    const bool q1 = mode == SF_ICP_P2PLANE && icp->qpl > 1 && icp->fz_step < VERIFY_FROM_SEARCH; // as enqueue_align: one query per lane while nearly every query searches
+    const int nb = q1 ? icp->own_nblocks * icp->qpl : icp->own_nblocks, B = icp->batch, K = icp->prm.num_iters, qpl_now = q1 ? 1 : icp->qpl;
     const bool fz_nn = freeze_nn_now(icp, mode), fz_solve = freeze_solve_now(icp, mode);
     if (mode == SF_ICP_O3D_P2P) launch_nn_red<1>(icp, true);
     else if (fz_nn) launch_nn_red_fz(icp, true, icp->fz_step > icp->fz_from);
-    else launch_nn_red<2>(icp, true);
+    else launch_nn_red<2>(icp, true, q1);
     {
         ProfScope ps(icp, SF_PROF_REDUCE);
         if (mode == SF_ICP_O3D_P2P) hipLaunchKernelGGL(k_reduce_publish<1>, dim3(B), dim3(SBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qpl, view, freeze_bufs(icp, false));
-        else hipLaunchKernelGGL(k_reduce_publish<2>, dim3(B), dim3(SBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), icp->qpl, view, freeze_bufs(icp, fz_nn));
+        else hipLaunchKernelGGL(k_reduce_publish<2>, dim3(B), dim3(SBLK), 0, s, st, icp->partials.as<double>(), nb, icp->own_off.as<uint32_t>(), qpl_now, view, freeze_bufs(icp, fz_nn));
     }
     {
         ProfScope ps(icp, SF_PROF_COLLECTIVE); // the wait for the peers' records AND the solve
