@@ -9,6 +9,12 @@ whole ICP with scans and map already resident in HBM.  `--mode`:
   ref_cpp  the C++ reference's ICPPointToPoint::calculateAlignment (icp_point_to_point.cpp:185-254) with the node's
            parameters 0.5 / 10 / 0.05 / 1e-5 (localization_node.cpp:24-28): lazy re-search, float32 point updates
 
+What the p2plane line quotes: `value` with the library's defaults -- exact NN result in every iteration, neighbour reuse on (a
+query whose neighbour provably cannot have changed skips its search) and frozen pairs on (once a scan's pairs are certified to
+stay, their sums are evaluated from moments instead of streaming the scan; same pairs, float64 sums equal to rounding).  Measured
+beside it in the same run: `value_no_freeze` (frozen pairs off), `value_no_reuse` (every query searches in every iteration),
+`value_32_in_flight`, `value_upload_inclusive`, `single_scan_latency_ms`, `value_stream_config4`.
+
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
