@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--query-order", default="auto", choices=["auto", "as_given", "cell"], help="sf_icp_set_query_order")
     ap.add_argument("--no-nn-reuse", action="store_true", help="sf_icp_set_nn_reuse(0): search every query in every iteration")
     ap.add_argument("--no-freeze", action="store_true", help="sf_icp_set_freeze(0): every launch of an alignment streams every query (rounds 1-3 up to here)")
+    ap.add_argument("--no-tile", action="store_true", help="sf_icp_set_tile_search(0): the searching launches walk the global grid index (rounds 1-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (no-reuse throughput, upload-inclusive rate, single-scan latency)")
     ap.add_argument("--no-graph", action="store_true")
@@ -202,6 +203,7 @@ def main():
         icp.set_query_order(args.query_order)
         icp.set_nn_reuse(not args.no_nn_reuse)
         icp.set_freeze(False if args.no_freeze else "auto")
+        icp.set_tile_search(False if args.no_tile else "auto")
         return icp
 
     # ---------------- the registration driver of this rank

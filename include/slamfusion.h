@@ -281,6 +281,19 @@ int sf_icp_set_query_order(sf_icp *icp, int order);
  * search is skipped.  Results are bit-identical with the switch on or off (tested); it only
  * changes how much of the "nearest neighbour every iteration" work has to be redone. */
 int sf_icp_set_nn_reuse(sf_icp *icp, int on);
+/* Tile search (O3D_P2P / P2PLANE launch list, scans above 131 072 points, whole map, unsharded, queries ordered): the
+ * launches of an alignment in which nearly every query searches -- the first four with the neighbour reuse on, all of them
+ * with it off -- run tile by tile: the scans' queries are sorted by map tile (a box of grid cells), one workgroup stages a
+ * tile's points and cell table in LDS and serves every query of every scan that falls into it from there; the pairs go
+ * through the neighbour cache and are summed in the usual order.  The exact search of icp_point_to_point.cpp:64-69 /
+ * localization_node.py:233-237, the same pairs and bit-identical sums as without (tested); what changes is that a
+ * candidate is an LDS read instead of a 16-byte access through the L1.  mode: 0 never, 1 (default) when the batch holds at
+ * least 2 M queries, 2 whenever the conditions above hold. */
+int sf_icp_set_tile_search(sf_icp *icp, int mode);
+/* out[0] = the last alignment used tile search; [1..3] cells per tile (x, y, z); [4..6] tiles per axis; with
+ * sf_icp_profile_enable: [7] queries that searched in the tile launches, [8] settled out of LDS, [9] walked the global
+ * index because they had left the staged region, [10] went on to ring 2 and beyond, [11] tiles too dense to stage */
+int sf_icp_tile_info(sf_icp *icp, int64_t out[12]);
 /* Frozen pairs (P2PLANE launch list, scans above 131 072 points, neighbour reuse on, whole map, unsharded): once a scan's
  * pairs are certified to stay as they are while it moves by a guard distance more, one launch forms the 96 moments of
  * those pairs and the iterations after it evaluate the normal equations from the moments (a polynomial in the pose)

@@ -544,6 +544,19 @@ class Icp:
         code = {False: 0, "off": 0, "auto": 1, True: 2, "always": 2}[on]
         _check(self.lib.sf_icp_set_freeze(self.h, C.c_int(code)))
 
+    def set_tile_search(self, on="auto"):
+        """Tile search (sf_icp_set_tile_search): the searching launches of large batches served out of LDS tile by tile, see
+        include/slamfusion.h.  False / "off", "auto" (default: batches of at least 2 M queries), True / "always"."""
+        code = {False: 0, "off": 0, "auto": 1, True: 2, "always": 2}[on]
+        _check(self.lib.sf_icp_set_tile_search(self.h, C.c_int(code)))
+
+    def tile_info(self):
+        """Of the last alignment (sf_icp_tile_info); the counters are filled while profiling is on."""
+        a = (C.c_int64 * 12)()
+        _check(self.lib.sf_icp_tile_info(self.h, a))
+        return {"on": bool(a[0]), "cells_per_tile": [a[1], a[2], a[3]], "tiles": [a[4], a[5], a[6]], "searched": a[7], "from_lds": a[8], "left_region": a[9],
+                "beyond_ring_1": a[10], "tiles_too_dense": a[11]}
+
     def set_freeze_params(self, guard_scale=8.0, guard_min=2.0e-5, guard_max=3.0e-4, max_tries=3, from_launch=5):
         _check(self.lib.sf_icp_set_freeze_params(self.h, C.c_float(guard_scale), C.c_float(guard_min), C.c_float(guard_max), C.c_int(max_tries), C.c_int(from_launch)))
 

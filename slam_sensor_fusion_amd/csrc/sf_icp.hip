@@ -27,6 +27,7 @@
 // active return immediately, so the launch list is static and graph-capturable.
 #include "sf_common.hpp"
 #include "sf_nn.hpp"
+#include "sf_tile.hpp"
 #include "sf_order.hpp"
 #include "sf_p2p.hpp"
 
@@ -642,7 +643,8 @@ __device__ __forceinline__ LanePair make_pair(const QueryIn &q, const sf::NNHit 
 template <int MODE, bool WINDOW, bool SHARD>
 __device__ __forceinline__ LanePair nn_pair(const SfGrid &g, const SfWindow &w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                             int n, int b, const IcpState *S, float thr, float xlo, float xhi, const uint32_t *__restrict__ own_off,
-                                            float4 *__restrict__ qcache, int64_t cache_n, int slot, int n_live, sf::WaveNN *ws, uint32_t *__restrict__ stats)
+                                            float4 *__restrict__ qcache, int64_t cache_n, int slot, int n_live, sf::WaveNN *ws, uint32_t *__restrict__ stats,
+                                            sf::PhaseClock *pc = nullptr)
 {
     // once the scan's entries have been written (every lane writes its entry in the first launch after a (re)start,
     // searched or not, so the cache is never reset) the cache streams are requested together with the scan point: one
@@ -664,8 +666,9 @@ __device__ __forceinline__ LanePair nn_pair(const SfGrid &g, const SfWindow &w, 
         atomicAdd(&sh[0], (uint32_t)__popcll(need_mask));
         atomicAdd(&sh[1], 1u);
     }
+    SF_PH(pc, 0);
     if (need_mask != 0ull) {
-        const sf::NNHit h = sf::nn_search_wave<WINDOW>(g, w, need, qx, qy, qz, thr, ws, seed);
+        const sf::NNHit h = sf::nn_search_wave<WINDOW>(g, w, need, qx, qy, qz, thr, ws, seed, pc);
         if (need) {
             hit = h;
             // only the winner's normal is fetched after the search; its coordinates come in registers
@@ -683,6 +686,7 @@ __device__ __forceinline__ LanePair nn_pair(const SfGrid &g, const SfWindow &w, 
         if (MODE == 2) qcache[(size_t)cache_n + o] = make_float4(0.f, 0.f, 0.f, 0.f);
         else ecache[o] = 0.0f;
     }
+    SF_PH(pc, 6);
     return make_pair(q, hit, tn);
 }
 
@@ -751,6 +755,9 @@ __device__ __forceinline__ void add_half(const PairTerms &t, int h, double (&v)[
     }
 }
 
+#ifdef SF_PHASE_TRACE
+__device__ unsigned long long g_phase_trace[sf::PH_SHARDS * sf::PH_SLOTS];
+#endif
 template <int MODE, bool WINDOW, bool SHARD, int Q>
 __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red(SfGrid g, SfWindow w, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
                                                 int n, const IcpState *__restrict__ st, float thr, float xlo, float xhi, double *__restrict__ partials, int nblocks,
@@ -780,6 +787,12 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red(SfGrid g, SfWindow
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // the pairs are kept, not their terms (13 against 36 registers per query across the next search); the terms are
     // formed once per half below
+#ifdef SF_PHASE_TRACE
+    sf::PhaseClock pclk, *pc = &pclk;
+    pclk.start();
+#else
+    sf::PhaseClock *pc = nullptr;
+#endif
     LanePair P[Q];
     // Q > 1, from the launch on in which most waves only verify: the loads of ALL the lane's queries go out together (one
     // round trip per wave, Q times the bytes in flight) and, if every lane of the wave certifies every one of its
@@ -805,7 +818,7 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red(SfGrid g, SfWindow
 #pragma unroll
         for (int u = 0; u < Q; ++u) {
             const int slot = bx * (BLK * Q) + u * BLK + (int)threadIdx.x;
-            P[u] = nn_pair<MODE, WINDOW, SHARD>(g, w, X0x, X0y, X0z, n, b, S, thr, xlo, xhi, own_off, qcache, cache_n, slot, n_live, &nn_ws[wv], stats);
+            P[u] = nn_pair<MODE, WINDOW, SHARD>(g, w, X0x, X0y, X0z, n, b, S, thr, xlo, xhi, own_off, qcache, cache_n, slot, n_live, &nn_ws[wv], stats, pc);
         }
     }
     // the lane's pairs added, reduced over the wave in two halves of 16 values (keeps the live
@@ -828,12 +841,21 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red(SfGrid g, SfWindow
             if ((lane & 3) == 0) stage[wv][16 * h + (lane >> 2)] = t0;
         }
     }
+    SF_PH(pc, 7);
     __syncthreads();
     if (threadIdx.x < NREC) {
         const int c = threadIdx.x;
         double *dst = partials + ((size_t)b * nblocks + bx) * REC_STRIDE;
         dst[c] = ((stage[0][c] + stage[1][c]) + stage[2][c]) + stage[3][c];
     }
+#ifdef SF_PHASE_TRACE
+    SF_PH(pc, 8);
+    pclk.count(14, 1u);
+    if (lane == 0) {
+        unsigned long long *dstp = g_phase_trace + (size_t)(L & (sf::PH_SHARDS - 1)) * sf::PH_SLOTS;
+        for (int i = 0; i < sf::PH_SLOTS; ++i) atomicAdd(&dstp[i], (unsigned long long)pclk.acc[i]);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ query order
@@ -926,6 +948,299 @@ __global__ __launch_bounds__(256) void k_order_gather(const float4 *__restrict__
             Xy[base + 256 * k] = v[k].y;
             Xz[base + 256 * k] = v[k].z;
         }
+}
+
+// ------------------------------------------------------------------ tile search (sf_tile.hpp): queries sorted by map tile, searched out of LDS
+// 20-bit tile key of global query o under the scan's current pose (sorted in two 10-bit digits: sf_order.hpp is a stable
+// counting pass, least significant digit first); non-finite queries carry the largest key and end up last in their scan
+constexpr uint32_t TILE_KEY_NONE = (1u << 20) - 1u;
+struct TileKeyFn {
+    SfGrid g;
+    sf::SfTiles tl;
+    const float *x, *y, *z;
+    const IcpState *st;
+    int n, digit;
+    struct Point { float x, y, z; };
+    struct Pose { float T[12]; };
+    __device__ __forceinline__ Pose prepare(int b) const
+    {
+        Pose P;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) P.T[k] = (float)st[b].T[k];
+        return P;
+    }
+    __device__ __forceinline__ Point load(uint32_t o) const { return Point{x[o], y[o], z[o]}; }
+    // (a locality key like CellKeyFn's: float32 arithmetic decides which of two tiles a query on their border is binned
+    // to -- the search itself takes the query's exact cell and only asks whether the staged region covers it)
+    __device__ __forceinline__ uint32_t full_key(const Pose &P, const Point &p) const
+    {
+        const float qx = fmaf(P.T[0], p.x, fmaf(P.T[1], p.y, fmaf(P.T[2], p.z, P.T[3])));
+        const float qy = fmaf(P.T[4], p.x, fmaf(P.T[5], p.y, fmaf(P.T[6], p.z, P.T[7])));
+        const float qz = fmaf(P.T[8], p.x, fmaf(P.T[9], p.y, fmaf(P.T[10], p.z, P.T[11])));
+        if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return TILE_KEY_NONE;
+        const int cx = (int)fminf(fmaxf(floorf((qx - g.org[0]) * g.inv_h), 0.0f), (float)(g.dim[0] - 1));
+        const int cy = (int)fminf(fmaxf(floorf((qy - g.org[1]) * g.inv_h), 0.0f), (float)(g.dim[1] - 1));
+        const int cz = (int)fminf(fmaxf(floorf((qz - g.org[2]) * g.inv_h), 0.0f), (float)(g.dim[2] - 1));
+        return sf::tile_of_cell(tl, cx, cy, cz);
+    }
+    __device__ __forceinline__ uint32_t key(const Pose &P, const Point &p) const { return (full_key(P, p) >> (sf::ORD_KEY_BITS * digit)) & (uint32_t)(sf::ORD_BINS - 1); }
+};
+
+__global__ __launch_bounds__(sf::ORD_BLK) void k_order_hist_tile(sf::OrderSrc s, TileKeyFn kf, uint16_t *__restrict__ keys, uint32_t *__restrict__ counts)
+{
+    sf::order_hist_body(s, kf, keys, counts);
+}
+
+// tile key of every query of the ORDERED arrays (kf.x / y / z = the ordered copy), scan by scan
+__global__ __launch_bounds__(256) void k_tile_keys(TileKeyFn kf, int64_t total, uint32_t *__restrict__ tkey)
+{
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int b = (int)(o / kf.n);
+    tkey[o] = kf.full_key(kf.prepare(b), kf.load((uint32_t)o));
+}
+
+// seg[t * batch + b] = first position in scan b's ordered queries whose tile key is >= t, for t in [0, ntiles] (tile-major:
+// the workgroup of tile t reads its `batch` starts and ends as two contiguous rows)
+__global__ __launch_bounds__(256) void k_tile_starts(const uint32_t *__restrict__ tkey, int n, int batch, int ntiles, uint32_t *__restrict__ seg)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)(ntiles + 1) * batch) return;
+    const uint32_t t = (uint32_t)(i / batch);
+    const int b = (int)(i % batch);
+    const uint32_t *k = tkey + (size_t)b * n;
+    int lo = 0, hi = n; // first position with key >= t
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (k[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    seg[i] = (uint32_t)lo;
+}
+
+// statistics of the tile launches (integers: order independent): [0] queries that searched, [1] of them settled out of LDS,
+// [2] walked the global index because the staged region did not cover them, [3] went on to ring 2 and beyond after the LDS
+// search, [4] tiles whose region did not fit
+constexpr int TILE_STATS = 8;
+#ifdef SF_PHASE_TRACE
+__device__ unsigned long long g_tile_trace[sf::PH_SHARDS * sf::PH_SLOTS];
+#define TT_MARK(i) do { if (wv == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tt_acc[i] += (unsigned)(n_ - tt_t); tt_t = n_; } } while (0)
+#else
+#define TT_MARK(i) do { } while (0)
+#endif
+
+// One workgroup per map tile: stage the tile, then the tile's queries of every scan in flight (certificate, search out of LDS,
+// cache entry).  No sums are formed here -- k_red_cached adds the pairs up from the cache in k_nn_red's order.
+template <int MODE>
+__global__ __launch_bounds__(sf::TILE_BLK) void k_tile_search(SfGrid g, sf::SfTiles tl, const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z,
+                                                              int n, int batch, const IcpState *__restrict__ st, float thr, const uint32_t *__restrict__ seg,
+                                                              float4 *__restrict__ qcache, int64_t cache_n, int reuse, unsigned long long *__restrict__ stats)
+{
+    // XCD-aware placement (as k_nn_red): linear id L runs on XCD L % 8; each XCD takes a contiguous eighth of the tiles,
+    // so neighbouring tiles -- which share their halos -- meet in one L2
+    const int per = ((int)gridDim.x) >> 3;
+    const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (tile >= tl.ntiles) return;
+    __shared__ sf::TileLds lds;
+    __shared__ double Tm[sf::TILE_SCANS][12];
+    __shared__ float mot[sf::TILE_SCANS];
+    __shared__ int live[sf::TILE_SCANS];
+    __shared__ uint32_t pre[sf::TILE_SCANS + 1], gofs[sf::TILE_SCANS];
+    __shared__ unsigned int cnt[4];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const sf::TileRegion R = sf::tile_region(g, tl, (uint32_t)tile);
+#ifdef SF_PHASE_TRACE
+    unsigned tt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tt_t = __builtin_amdgcn_s_memtime();
+#endif
+    bool staged = false, fits = false;
+    if (tid < 4) cnt[tid] = 0;
+    float *ecache = reinterpret_cast<float *>(qcache + (size_t)cache_n);
+    SfWindow nowin;
+    nowin.kind = 0;
+    for (int b0 = 0; b0 < batch; b0 += sf::TILE_SCANS) {
+        __syncthreads(); // the previous group's tables are no longer read
+        if (wv == 0) {
+            const int b = b0 + lane;
+            uint32_t s0 = 0, len = 0;
+            if (b < batch && !st[b].done) {
+                s0 = seg[(size_t)tile * batch + b];
+                len = seg[(size_t)(tile + 1) * batch + b] - s0;
+            }
+            uint32_t v = len;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)v, o);
+                if (lane >= o) v += t;
+            }
+            pre[lane + 1] = v;
+            if (lane == 0) pre[0] = 0;
+            gofs[lane] = (uint32_t)((size_t)b * n + s0);
+        }
+        for (int i = tid; i < sf::TILE_SCANS * 12; i += sf::TILE_BLK) {
+            const int b = b0 + i / 12;
+            Tm[i / 12][i % 12] = b < batch ? st[b].T[i % 12] : 0.0;
+        }
+        if (tid < sf::TILE_SCANS) {
+            const int b = b0 + tid;
+            mot[tid] = b < batch ? (float)st[b].motion : 0.0f;
+            live[tid] = (b < batch && reuse && st[b].cache_live != 0) ? 1 : 0;
+        }
+        __syncthreads();
+        TT_MARK(0);
+        const uint32_t total = pre[sf::TILE_SCANS];
+        if (total == 0) continue; // (uniform)
+        if (!staged) { // only tiles that hold queries are staged
+            fits = sf::tile_stage(g, R, &lds);
+            staged = true;
+            if (!fits && tid == 0 && stats) atomicAdd(&stats[4], 1ull);
+        }
+        TT_MARK(1);
+        for (uint32_t i = (uint32_t)tid; i < total; i += sf::TILE_BLK) {
+            // the scan this query belongs to: the last prefix not above i
+            int bl = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) bl += (pre[bl + step] <= i) ? step : 0;
+            const size_t o = (size_t)gofs[bl] + (size_t)(i - pre[bl]);
+            const bool cache_live = live[bl] != 0;
+            float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), c2 = c1;
+            float e = 0.0f;
+            if (cache_live) {
+                c1 = qcache[o];
+                if (MODE == 2) { c2 = qcache[(size_t)cache_n + o]; e = c2.w; }
+                else e = ecache[o];
+            }
+            const double x0 = X0x[o], y0 = X0y[o], z0 = X0z[o];
+            const double *T = Tm[bl];
+            const double sx = T[0] * x0 + T[1] * y0 + T[2] * z0 + T[3];
+            const double sy = T[4] * x0 + T[5] * y0 + T[6] * z0 + T[7];
+            const double sz = T[8] * x0 + T[9] * y0 + T[10] * z0 + T[11];
+            const float qx = (float)sx, qy = (float)sy, qz = (float)sz;
+            const float m_now = mot[bl];
+            sf::NNHit chit, seed;
+            float4 tn;
+            bool need = reuse_certificate(true, qx, qy, qz, thr, m_now, e, c1, c2, chit, tn, seed);
+            if (!need) {
+                if (!cache_live) { // first launch after a (re)start: a lane that does not search (non-finite query) leaves "no search behind it"
+                    if (MODE == 2) qcache[(size_t)cache_n + o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else ecache[o] = 0.0f;
+                }
+                continue;
+            }
+            // what nn_search_wave does before it walks: a query farther from the map's box than the acceptance radius has no neighbour
+            sf::NNHit hit;
+            hit.d2 = sf::search_start(thr);
+            hit.j = -1;
+            hit.px = hit.py = hit.pz = 0.0f;
+            hit.lb2 = 3.0e38f;
+            bool walk = g.n > 0;
+            {
+                const float ox = fmaxf(fmaxf(g.org[0] - qx, qx - (g.org[0] + (float)g.dim[0] * g.h)), 0.0f);
+                const float oy = fmaxf(fmaxf(g.org[1] - qy, qy - (g.org[1] + (float)g.dim[1] * g.h)), 0.0f);
+                const float oz = fmaxf(fmaxf(g.org[2] - qz, qz - (g.org[2] + (float)g.dim[2] * g.h)), 0.0f);
+                const float gap = fmaxf(sqrtf(ox * ox + oy * oy + oz * oz) * 0.9995f - 1.0e-3f, 0.0f);
+                if (gap * gap > thr) { hit.lb2 = gap * gap; walk = false; }
+            }
+            if (walk) {
+                const sf::QueryGeo G = sf::query_geo(g, qx, qy, qz);
+                int ring_from = 1; // 0: settled out of LDS
+                if (fits && sf::tile_serves(g, R, G)) {
+                    bool more;
+                    const sf::TileHit th = sf::tile_search(g, R, &lds, G, qx, qy, qz, thr, seed.d2, seed.j, &more);
+                    hit.d2 = th.d2; hit.j = th.j; hit.lb2 = th.lb2;
+                    if (th.loc >= 0) { const float4 p = lds.pts[th.loc]; hit.px = p.x; hit.py = p.y; hit.pz = p.z; }
+                    else if (th.j >= 0) { hit.px = seed.px; hit.py = seed.py; hit.pz = seed.pz; }
+                    ring_from = more ? 2 : 0; // more: no map point within the boundary of the 27 cells (rare)
+                    if (stats) atomicAdd(&cnt[more ? 3 : 1], 1u);
+                } else { // the query has left what this tile staged (or the tile did not fit): the global index, lane by lane
+                    if (seed.j >= 0 && seed.d2 < thr) { hit.d2 = seed.d2; hit.j = seed.j; hit.px = seed.px; hit.py = seed.py; hit.pz = seed.pz; }
+                    if (stats) atomicAdd(&cnt[2], 1u);
+                }
+                if (ring_from) {
+                    sf::nn_rings<false>(g, nowin, qx, qy, qz, ring_from, hit);
+                    hit.lb2 = 0.0f; // no bound kept for the per-lane rings
+                }
+            }
+            if (stats) atomicAdd(&cnt[0], 1u);
+            float4 nrm = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == 2 && hit.j >= 0) nrm = g.nrm[hit.j];
+            const float en = fmaxf(sqrtf(hit.lb2) * 0.9999f + m_now * 0.999998f - 1.0e-6f, 1.0e-30f);
+            qcache[o] = make_float4(hit.px, hit.py, hit.pz, __int_as_float(hit.j));
+            if (MODE == 2) qcache[(size_t)cache_n + o] = make_float4(nrm.x, nrm.y, nrm.z, en);
+            else ecache[o] = en;
+        }
+    }
+    TT_MARK(2);
+    __syncthreads();
+    TT_MARK(3);
+    if (stats && tid < 4 && cnt[tid]) atomicAdd(&stats[tid], (unsigned long long)cnt[tid]);
+#ifdef SF_PHASE_TRACE
+    if (tid == 0) {
+        tt_acc[7] = 1;
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_tile_trace[(size_t)(blockIdx.x & (sf::PH_SHARDS - 1)) * sf::PH_SLOTS + i], (unsigned long long)tt_acc[i]);
+    }
+#endif
+}
+
+// The records of one launch from the neighbour cache alone (every entry is a pair that holds at the current pose: k_tile_search
+// has just certified or searched it): rows, summation order and arithmetic of k_nn_red<MODE, false, false, Q> -- the sums are
+// bit-identical to what k_nn_red forms from the same pairs.
+template <int MODE, int Q>
+__global__ __launch_bounds__(BLK) void k_red_cached(const float *__restrict__ X0x, const float *__restrict__ X0y, const float *__restrict__ X0z, int n,
+                                                    const IcpState *__restrict__ st, float thr, double *__restrict__ partials, int nblocks, const float4 *__restrict__ qcache,
+                                                    int64_t cache_n)
+{
+    constexpr int NREC = MODE == 2 ? NREC_PLANE : NREC_P2P;
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int kk = L >> 3;
+    const int b = kk % (int)gridDim.y;
+    const int bx = (L & 7) * ((int)gridDim.x >> 3) + kk / (int)gridDim.y;
+    if (bx >= nblocks) return;
+    const IcpState *S = st + b;
+    if (S->done) return;
+    __shared__ double stage[BLK / 64][32];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    LanePair P[Q];
+#pragma unroll
+    for (int u = 0; u < Q; ++u) {
+        const int slot = bx * (BLK * Q) + u * BLK + (int)threadIdx.x;
+        const QueryIn q = query_in<MODE, false>(X0x, X0y, X0z, n, b, S, 0.0f, 0.0f, nullptr, qcache, cache_n, true, slot, n);
+        sf::NNHit hit;
+        hit.d2 = thr;
+        hit.j = -1;
+        hit.px = hit.py = hit.pz = 0.0f;
+        hit.lb2 = 0.0f;
+        float4 tn = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int32_t jc = __float_as_int(q.c1.w);
+        if (slot < n && jc >= 0 && isfinite(q.qx) && isfinite(q.qy) && isfinite(q.qz)) {
+            const float d2n = sf::l2_simple(q.qx, q.qy, q.qz, q.c1.x, q.c1.y, q.c1.z);
+            if (d2n < thr) { hit.d2 = d2n; hit.j = jc; hit.px = q.c1.x; hit.py = q.c1.y; hit.pz = q.c1.z; tn = q.c2; }
+        }
+        P[u] = make_pair(q, hit, tn);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 0.0;
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+            const PairTerms t = pair_terms<MODE>(P[u]);
+            add_half<MODE>(t, h, v);
+        }
+        if (MODE == 1 && h == 1) {
+            const double t1 = wave_reduce_1(v[0]);
+            if (lane == 0) stage[wv][16] = t1;
+        } else {
+            const double t0 = wave_reduce_16(v);
+            if ((lane & 3) == 0) stage[wv][16 * h + (lane >> 2)] = t0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NREC) {
+        const int c = threadIdx.x;
+        double *dst = partials + ((size_t)b * nblocks + bx) * REC_STRIDE;
+        dst[c] = ((stage[0][c] + stage[1][c]) + stage[2][c]) + stage[3][c];
+    }
 }
 
 // ------------------------------------------------------------------ sharded path: owned queries
@@ -2611,6 +2926,11 @@ struct sf_icp {
     sf::DevBuf fz_state, fz_part, fz_cnt, fz_ids, fz_all;
     int64_t nn_stats_used = 0;
     static constexpr int64_t NN_STATS_CAP = 1024;
+    // tile search (sf_tile.hpp): the searching launches of large batches
+    int tile_mode = 0;              // sf_icp_set_tile_search: 0 off, 1 when the batch is large enough to gain (TILE_AUTO_MIN_QUERIES), 2 whenever possible
+    bool tile_on = false;           // this alignment's queries are sorted by tile and its searching launches run k_tile_search
+    sf::SfTiles tiles{};
+    sf::DevBuf qtkey, tseg, tile_stats; // tile key of every ordered query; per (tile, scan) segment starts; counters
 };
 
 namespace {
@@ -2640,7 +2960,7 @@ int order_key_shift(const SfGrid &g)
 // neighbour reuse starts empty at every alignment (a zero bound certifies nothing)
 int reuse_reset(sf_icp *icp, int64_t count)
 {
-    if (!icp->reuse) return SF_OK;
+    if (!icp->reuse && !icp->tile_on) return SF_OK; // (tile launches hand their pairs to k_red_cached through the cache arrays)
     const size_t c = (size_t)std::max<int64_t>(count, 1);
     // nothing is cleared: a scan's entries count only once IcpState::cache_live says they have been written (every lane
     // writes its entry in the first launch after a start or a rebuild of the owned arrays)
@@ -2649,12 +2969,66 @@ int reuse_reset(sf_icp *icp, int64_t count)
     return SF_OK;
 }
 
+// ---- tile search: which alignments, which tiles
+// The searching launches of a batch go tile by tile when there is enough work to amortise staging every tile that holds a
+// query and the second sorting pass (measured break-even: TILE_AUTO_MIN_QUERIES), on the whole map (no window), unsharded,
+// with the queries ordered.  Tile shape: cells per axis such that the staged region (core + 2 cells all round) holds about
+// 3/4 of TILE_PCAP points at the map's mean density -- 8 x 8 x 4 cells at the metric configuration (0.25 m cells, 1.5 points
+// per cell: 12 x 12 x 8 = 1 152 staged cells, ~1 700 points) -- within the limits of the LDS tables.
+constexpr int64_t TILE_AUTO_MIN_QUERIES = 2000000;
+bool tile_plan(const SfGrid &g, sf::SfTiles *out)
+{
+    const double ncell = (double)g.dim[0] * (double)g.dim[1] * (double)g.dim[2];
+    if (g.n <= 0 || ncell <= 0) return false;
+    const double density = (double)g.n / ncell; // points per cell (empty space included: an upper-bound-free mean; denser tiles fall back one by one)
+    int tc[3] = {8, 8, 4};
+    auto region_cells = [&](const int *c) { return (double)(c[0] + 2 * sf::TILE_HALO) * (c[1] + 2 * sf::TILE_HALO) * (c[2] + 2 * sf::TILE_HALO); };
+    auto fits_tables = [&](const int *c) { return c[0] + 2 * sf::TILE_HALO <= sf::TILE_RX_MAX && (c[1] + 2 * sf::TILE_HALO) * (c[2] + 2 * sf::TILE_HALO) <= sf::TILE_ROWS_MAX; };
+    const double budget = 0.75 * sf::TILE_PCAP;
+    while (region_cells(tc) * density > budget) { // shrink the longest axis
+        int a = tc[0] >= tc[1] && tc[0] >= tc[2] ? 0 : (tc[1] >= tc[2] ? 1 : 2);
+        if (tc[a] <= 2) return false; // too dense for any tile: the global index
+        tc[a] /= 2;
+    }
+    for (;;) { // grow the shortest axis while there is room (sparse maps)
+        int a = tc[2] <= tc[1] && tc[2] <= tc[0] ? 2 : (tc[1] <= tc[0] ? 1 : 0);
+        int t2[3] = {tc[0], tc[1], tc[2]};
+        t2[a] *= 2;
+        if (!fits_tables(t2) || region_cells(t2) * density > budget) break;
+        tc[0] = t2[0]; tc[1] = t2[1]; tc[2] = t2[2];
+    }
+    if (!fits_tables(tc)) return false;
+    sf::SfTiles tl;
+    int64_t nt = 1;
+    for (int a = 0; a < 3; ++a) {
+        tl.tc[a] = tc[a];
+        tl.nt[a] = (g.dim[a] + tc[a] - 1) / tc[a];
+        nt *= tl.nt[a];
+    }
+    if (nt >= (int64_t)TILE_KEY_NONE) return false;
+    tl.ntiles = (int)nt;
+    *out = tl;
+    return true;
+}
+
+bool tile_wanted(const sf_icp *icp, int mode)
+{
+    if (icp->tile_mode == 0 || icp->shard || icp->map->window.kind != 0 || (mode != SF_ICP_P2PLANE && mode != SF_ICP_O3D_P2P)) return false;
+    if (icp->qpl == 1) return false; // scans the single-launch kernels can take keep their summation order (and their launch list)
+    return icp->tile_mode == 2 || icp->n * icp->batch >= TILE_AUTO_MIN_QUERIES;
+}
+
+// launches of an alignment that run tile by tile: those in which nearly every query searches -- all of them with the neighbour
+// reuse off, the first VERIFY_FROM_SEARCH with it on (afterwards whole waves certify and k_nn_red streams the cache)
+bool tile_launch(const sf_icp *icp, int k) { return icp->tile_on && (!icp->reuse || k < VERIFY_FROM_SEARCH); }
+
 // the segmented stable bucket sort of sf_order.hpp: nseg segments (uniform: nseg scans of icp->n queries; sharded: the
 // owned-query candidates of each scan, seg_off / src_idx on the device), `longest` = the longest segment
 int run_order_sort(sf_icp *icp, int nseg, int64_t longest, int64_t total, const uint32_t *seg_off, const uint32_t *src_idx)
 {
     const SfGrid &g = icp->map->grid;
     const int64_t all = icp->n * icp->batch;
+    if (seg_off) icp->tile_on = false; // (the sharded path's owned-query arrays keep the cell order)
     sf::OrderSrc src;
     src.src_idx = src_idx;
     src.seg_off = seg_off;
@@ -2676,9 +3050,34 @@ int run_order_sort(sf_icp *icp, int nseg, int64_t longest, int64_t total, const 
     hipStream_t s = icp->ctx->stream;
     src.nseg = nseg;
     const dim3 grid(sf::order_grid(src.tiles, nseg)), blk(sf::ORD_BLK);
-    hipLaunchKernelGGL(k_order_hist, grid, blk, 0, s, src, kf, keys, counts);
-    hipLaunchKernelGGL(sf::k_order_scan, dim3((unsigned)nseg), dim3(sf::ORD_BINS), 0, s, counts, src.tiles);
-    hipLaunchKernelGGL(k_order_scatter, grid, blk, 0, s, src, keys, counts, ordered);
+    if (icp->tile_on) { // by map tile: a 20-bit key, least significant 10-bit digit first (stable passes)
+        TileKeyFn tk;
+        tk.g = g; tk.tl = icp->tiles;
+        tk.x = kf.x; tk.y = kf.y; tk.z = kf.z;
+        tk.st = kf.st; tk.n = (int)icp->n;
+        const bool two = icp->tiles.ntiles > sf::ORD_BINS;
+        uint32_t *first = ordered;
+        if (two) {
+            SF_TRY(icp->qidx2.reserve(sizeof(uint32_t) * cap));
+            first = icp->qidx2.as<uint32_t>();
+        }
+        tk.digit = 0;
+        hipLaunchKernelGGL(k_order_hist_tile, grid, blk, 0, s, src, tk, keys, counts);
+        hipLaunchKernelGGL(sf::k_order_scan, dim3((unsigned)nseg), dim3(sf::ORD_BINS), 0, s, counts, src.tiles);
+        hipLaunchKernelGGL(k_order_scatter, grid, blk, 0, s, src, keys, counts, first);
+        if (two) {
+            sf::OrderSrc src2 = src;
+            src2.src_idx = first;
+            tk.digit = 1;
+            hipLaunchKernelGGL(k_order_hist_tile, grid, blk, 0, s, src2, tk, keys, counts);
+            hipLaunchKernelGGL(sf::k_order_scan, dim3((unsigned)nseg), dim3(sf::ORD_BINS), 0, s, counts, src2.tiles);
+            hipLaunchKernelGGL(k_order_scatter, grid, blk, 0, s, src2, keys, counts, ordered);
+        }
+    } else {
+        hipLaunchKernelGGL(k_order_hist, grid, blk, 0, s, src, kf, keys, counts);
+        hipLaunchKernelGGL(sf::k_order_scan, dim3((unsigned)nseg), dim3(sf::ORD_BINS), 0, s, counts, src.tiles);
+        hipLaunchKernelGGL(k_order_scatter, grid, blk, 0, s, src, keys, counts, ordered);
+    }
     const int64_t qplane = seg_off ? total : icp->plane; // sharded: the compact arrays have their own length
     if (seg_off) {
         hipLaunchKernelGGL(k_order_gather, dim3(nblk(total, GATHER_TILE)), dim3(256), 0, s, icp->X0r.as<float4>(), ordered, total, 0, 0, 0, soa(icp->Xq, qplane, 0),
@@ -2687,6 +3086,19 @@ int run_order_sort(sf_icp *icp, int nseg, int64_t longest, int64_t total, const 
         const int gt = (int)std::max<int64_t>(1, sf::div_up(icp->n, GATHER_TILE));
         hipLaunchKernelGGL(k_order_gather, dim3(sf::order_grid(gt, nseg)), dim3(256), 0, s, icp->X0r.as<float4>(), ordered, total, (int)icp->n, gt, nseg,
                            soa(icp->Xq, qplane, 0), soa(icp->Xq, qplane, 1), soa(icp->Xq, qplane, 2));
+    }
+    if (icp->tile_on) { // where each tile's queries start in every scan's ordered array
+        TileKeyFn tk;
+        tk.g = g; tk.tl = icp->tiles;
+        tk.x = soa(icp->Xq, qplane, 0); tk.y = soa(icp->Xq, qplane, 1); tk.z = soa(icp->Xq, qplane, 2);
+        tk.st = kf.st; tk.n = (int)icp->n; tk.digit = 0;
+        const int64_t rows = (int64_t)icp->tiles.ntiles + 1;
+        SF_TRY(icp->qtkey.reserve(sizeof(uint32_t) * cap));
+        SF_TRY(icp->tseg.reserve(sizeof(uint32_t) * (size_t)rows * (size_t)nseg));
+        SF_TRY(icp->tile_stats.reserve(sizeof(unsigned long long) * TILE_STATS));
+        SF_HIP(hipMemsetAsync(icp->tile_stats.p, 0, sizeof(unsigned long long) * TILE_STATS, s));
+        hipLaunchKernelGGL(k_tile_keys, dim3(nblk(total)), dim3(256), 0, s, tk, total, icp->qtkey.as<uint32_t>());
+        hipLaunchKernelGGL(k_tile_starts, dim3(nblk(rows * nseg)), dim3(256), 0, s, icp->qtkey.as<uint32_t>(), (int)icp->n, nseg, icp->tiles.ntiles, icp->tseg.as<uint32_t>());
     }
     SF_HIP(hipGetLastError());
     return SF_OK;
@@ -2697,7 +3109,9 @@ int order_queries(sf_icp *icp, int mode)
     const int64_t total = icp->n * icp->batch;
     const bool want = icp->order == SF_ORDER_CELL || (icp->order == SF_ORDER_AUTO && total >= ORDER_AUTO_MIN_QUERIES);
     icp->ordered = false;
+    icp->tile_on = false;
     if (!want || total == 0 || icp->map->grid.n == 0 || icp->n_on_device) return SF_OK; // (a count left on the device: the tail of the arrays is not data)
+    icp->tile_on = tile_wanted(icp, mode) && tile_plan(icp->map->grid, &icp->tiles);
     SF_TRY(run_order_sort(icp, icp->batch, icp->n, total, nullptr, nullptr));
     icp->ordered = true;
     return SF_OK;
@@ -2800,13 +3214,13 @@ void prof_collect(sf_icp *icp)
 sf_icp::GraphKey graph_key_now(const sf_icp *icp, int mode)
 {
     sf_icp::GraphKey k;
-    k.mode = mode; k.iters = icp->prm.num_iters; k.batch = icp->batch; k.window = icp->map->window.kind; k.ordered = (int)icp->ordered; k.reuse = (int)icp->reuse | (icp->freeze << 1) | (icp->fz_from << 3);
+    k.mode = mode; k.iters = icp->prm.num_iters; k.batch = icp->batch; k.window = icp->map->window.kind; k.ordered = (int)icp->ordered | ((int)icp->tile_on << 1); k.reuse = (int)icp->reuse | (icp->freeze << 1) | (icp->fz_from << 3);
     k.n = (mode == SF_ICP_REF_CPP && icp->batch == 1) ? -icp->n_cap : icp->n; // REF_CPP, one scan: any count of the same capacity replays
     k.map = (const void *)icp->map;
     k.map_generation = icp->map->generation;
     k.max_corr = icp->prm.max_corr; k.accept = icp->prm.accept; k.eps = icp->prm.eps + icp->fz_prm.guard_scale * 1.0e-3f + icp->fz_prm.guard_min + icp->fz_prm.guard_max + (float)icp->fz_prm.max_tries; // (the freeze parameters travel by value too)
     const sf::DevBuf *bufs[] = {&icp->X0, &icp->X0r, &icp->X, &icp->Xq, &icp->qcache, &icp->corr, &icp->state, &icp->partials, &icp->d_box, &icp->d_boxes, &icp->n_dev,
-                                &icp->map->pts4, &icp->map->nrm4, &icp->map->cell_start, &icp->map->d_window, &icp->fz_state, &icp->fz_part, &icp->fz_cnt, &icp->fz_ids, &icp->fz_all};
+                                &icp->map->pts4, &icp->map->nrm4, &icp->map->cell_start, &icp->map->d_window, &icp->fz_state, &icp->fz_part, &icp->fz_cnt, &icp->fz_ids, &icp->fz_all, &icp->tseg, &icp->tile_stats};
     k.epochs = (uint64_t)icp->plane;
     for (const sf::DevBuf *b : bufs) k.epochs = k.epochs * 1000003ull + b->epoch;
     return k;
@@ -2845,6 +3259,30 @@ void launch_nn_red(sf_icp *icp, bool sharded = false, bool one_per_lane = false)
     else SF_LAUNCH_NNRED(false, false);
 #undef SF_LAUNCH_NNRED_Q
 #undef SF_LAUNCH_NNRED
+}
+
+// a searching launch tile by tile: k_tile_search leaves every query's pair in the neighbour cache, k_red_cached sums them in
+// k_nn_red's order (the same records, bit for bit)
+template <int MODE>
+void launch_tile_search(sf_icp *icp, bool one_per_lane)
+{
+    sf_map *m = icp->map;
+    const int nb = one_per_lane ? icp->nblocks : icp->nblocks_nn;
+    const float *x = src(icp, 0), *y = src(icp, 1), *z = src(icp, 2);
+    const IcpState *st = icp->state.as<IcpState>();
+    const float thr = o3d_thr(icp);
+    hipStream_t s = icp->ctx->stream;
+    ProfScope ps(icp);
+    unsigned long long *stats = icp->profiling ? icp->tile_stats.as<unsigned long long>() : nullptr;
+    if (icp->profiling && icp->nn_stats.p && icp->nn_stats_used < sf_icp::NN_STATS_CAP) icp->nn_stats_used++; // (keeps the per-launch statistics slots of k_nn_red aligned with the launch list)
+    const unsigned tgrid = (unsigned)((icp->tiles.ntiles + 7) & ~7);
+    hipLaunchKernelGGL((k_tile_search<MODE>), dim3(tgrid), dim3(sf::TILE_BLK), 0, s, m->grid, icp->tiles, x, y, z, (int)icp->n, icp->batch, st, thr, icp->tseg.as<uint32_t>(),
+                       icp->qcache.as<float4>(), icp->cache_n, (int)icp->reuse, stats);
+    const dim3 grid((unsigned)((nb + 7) & ~7), (unsigned)icp->batch), blk(BLK);
+    if (icp->qpl == 1 || one_per_lane)
+        hipLaunchKernelGGL((k_red_cached<MODE, 1>), grid, blk, 0, s, x, y, z, (int)icp->n, st, thr, icp->partials.as<double>(), nb, icp->qcache.as<float4>(), icp->cache_n);
+    else
+        hipLaunchKernelGGL((k_red_cached<MODE, SF_WIDE_QPL>), grid, blk, 0, s, x, y, z, (int)icp->n, st, thr, icp->partials.as<double>(), nb, icp->qcache.as<float4>(), icp->cache_n);
 }
 
 // frozen pairs: P2PLANE launch list of wide scans with the neighbour reuse on, whole map; sharded: each rank freezes its own
@@ -2974,7 +3412,8 @@ int enqueue_align(sf_icp *icp, int mode)
     const int n = (int)icp->n;
     if (mode == SF_ICP_O3D_P2P) {
         for (int k = 0; k <= K; ++k) {
-            launch_nn_red<1>(icp);
+            if (tile_launch(icp, k)) launch_tile_search<1>(icp, false);
+            else launch_nn_red<1>(icp);
             hipLaunchKernelGGL(k_reduce_solve<1>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K, icp->d_boxes.as<ScanBox>());
         }
     } else if (mode == SF_ICP_P2PLANE) {
@@ -2988,6 +3427,7 @@ int enqueue_align(sf_icp *icp, int mode)
         for (int k = 0; k < K; ++k) {
             const bool q1 = wide && k < VERIFY_FROM_SEARCH; // (the same schedule with the reuse off: it is part of the summation order, and reuse on == off bit for bit)
             if (fz && k >= icp->fz_from) launch_nn_red_fz(icp, false, k > icp->fz_from);
+            else if (tile_launch(icp, k)) launch_tile_search<2>(icp, q1);
             else launch_nn_red<2>(icp, false, q1);
             if (q1)
                 hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks, n, k, K, icp->d_boxes.as<ScanBox>());
@@ -3409,6 +3849,30 @@ extern "C" int sf_icp_set_nn_reuse(sf_icp *icp, int on)
     return SF_OK;
 }
 
+extern "C" int sf_icp_set_tile_search(sf_icp *icp, int mode)
+{
+    SF_CHECK(icp && mode >= 0 && mode <= 2, SF_ERR_INVALID, "bad arguments");
+    icp->tile_mode = mode;
+    return SF_OK;
+}
+
+extern "C" int sf_icp_tile_info(sf_icp *icp, int64_t out[12])
+{
+    SF_CHECK(icp && out, SF_ERR_INVALID, "bad arguments");
+    for (int i = 0; i < 12; ++i) out[i] = 0;
+    out[0] = icp->tile_on ? 1 : 0;
+    if (!icp->tile_on) return SF_OK;
+    for (int a = 0; a < 3; ++a) { out[1 + a] = icp->tiles.tc[a]; out[4 + a] = icp->tiles.nt[a]; }
+    if (icp->tile_stats.p) {
+        SF_HIP(hipSetDevice(icp->ctx->device));
+        unsigned long long h[TILE_STATS];
+        SF_HIP(hipMemcpyAsync(h, icp->tile_stats.p, sizeof(h), hipMemcpyDeviceToHost, icp->ctx->stream));
+        SF_HIP(hipStreamSynchronize(icp->ctx->stream));
+        for (int i = 0; i < 5; ++i) out[7 + i] = (int64_t)h[i];
+    }
+    return SF_OK;
+}
+
 extern "C" int sf_icp_set_freeze(sf_icp *icp, int on)
 {
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
@@ -3462,6 +3926,27 @@ extern "C" int sf_icp_set_fused(sf_icp *icp, int on)
     return SF_OK;
 }
 
+#ifdef SF_PHASE_TRACE
+extern "C" int sf_icp_tile_trace(unsigned long long *out)
+{
+    unsigned long long h[sf::PH_SHARDS * sf::PH_SLOTS];
+    if (hipDeviceSynchronize() != hipSuccess) return SF_ERR_HIP;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile_trace), sizeof(h)) != hipSuccess) return SF_ERR_HIP;
+    for (int i = 0; i < sf::PH_SLOTS; ++i) { out[i] = 0; for (int s = 0; s < sf::PH_SHARDS; ++s) out[i] += h[s * sf::PH_SLOTS + i]; }
+    memset(h, 0, sizeof(h));
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace), h, sizeof(h)) == hipSuccess ? SF_OK : SF_ERR_HIP;
+}
+// reads and clears the per-phase tick sums of the k_nn_red launches since the last call (diagnostic build only)
+extern "C" int sf_icp_phase_trace(unsigned long long *out)
+{
+    unsigned long long h[sf::PH_SHARDS * sf::PH_SLOTS];
+    if (hipDeviceSynchronize() != hipSuccess) return SF_ERR_HIP;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_trace), sizeof(h)) != hipSuccess) return SF_ERR_HIP;
+    for (int i = 0; i < sf::PH_SLOTS; ++i) { out[i] = 0; for (int s = 0; s < sf::PH_SHARDS; ++s) out[i] += h[s * sf::PH_SLOTS + i]; }
+    memset(h, 0, sizeof(h));
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_trace), h, sizeof(h)) == hipSuccess ? SF_OK : SF_ERR_HIP;
+}
+#endif
 #ifdef SF_FUSED_TRACE
 extern "C" int sf_icp_fused_trace(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_trace), sizeof(unsigned long long) * 512) == hipSuccess ? SF_OK : SF_ERR_HIP; }
 #endif

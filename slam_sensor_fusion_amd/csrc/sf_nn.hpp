@@ -34,6 +34,25 @@
 
 namespace sf {
 
+// SF_PHASE_TRACE (diagnostic build only, tools/phase_trace.py): s_memtime stamps at the phase boundaries of a searching
+// wave, summed per phase over the launch.  No stamp executes in the product build.
+#ifdef SF_PHASE_TRACE
+constexpr int PH_SLOTS = 16, PH_SHARDS = 64;
+struct PhaseClock {
+    unsigned long long t;
+    unsigned acc[PH_SLOTS];
+    __device__ __forceinline__ void start() { for (int i = 0; i < PH_SLOTS; ++i) acc[i] = 0; t = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void mark(int i) { const unsigned long long n = __builtin_amdgcn_s_memtime(); acc[i] += (unsigned)(n - t); t = n; }
+    __device__ __forceinline__ void count(int i, unsigned v) { acc[i] += v; }
+};
+#define SF_PH(pc, i) do { if (pc) (pc)->mark(i); } while (0)
+#define SF_PHC(pc, i, v) do { if (pc) (pc)->count(i, v); } while (0)
+#else
+struct PhaseClock {};
+#define SF_PH(pc, i) do { } while (0)
+#define SF_PHC(pc, i, v) do { } while (0)
+#endif
+
 struct NNHit {
     float d2;         // squared distance of the best candidate (the largest float below the threshold if none)
     int j;            // sorted position of the best candidate, -1 if none
@@ -166,6 +185,8 @@ __device__ __forceinline__ void scan_range(const SfGrid &g, const SfWindow &w, u
 {
     for (uint32_t j = a; j < b; j += 4) scan4<WINDOW, TRACK>(g, w, j, b, qx, qy, qz, hit);
 }
+
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); } // one v_min3_f32
 
 // cell_start[c-1 .. c+2] in ONE 16-byte load (the table carries one pad entry in front, so
 // c - 1 >= -1 is addressable; dword alignment is enough for global_load_dwordx4)
@@ -404,7 +425,8 @@ __device__ __forceinline__ float row_gap2(const QueryGeo &G, int k)
 // its range is scanned), most neighbour ranges pruned before they are visited.
 // COOP: how the rare queries that need more than ring 1 go on (see the end of the function)
 template <bool WINDOW, bool COOP = false>
-__device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow &w, bool valid, float qx, float qy, float qz, float thr, WaveNN *ws, NNHit seed = NNHit{0.0f, -1, 0.0f, 0.0f, 0.0f, 0.0f})
+__device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow &w, bool valid, float qx, float qy, float qz, float thr, WaveNN *ws, NNHit seed = NNHit{0.0f, -1, 0.0f, 0.0f, 0.0f, 0.0f},
+                                               PhaseClock *pc = nullptr)
 {
     const int lane = (int)__lane_id();
     const int nx = g.dim[0], ny = g.dim[1], nz = g.dim[2];
@@ -436,11 +458,25 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
     }
     if (valid && seed.j >= 0 && seed.d2 < thr) { hit.d2 = seed.d2; hit.j = seed.j; hit.px = seed.px; hit.py = seed.py; hit.pz = seed.pz; }
     uint32_t mask = 0;
+#ifdef SF_PHASE_TRACE
+    QueryGeo G{};
+    RowBounds rb0{0, 0, 0, 0};
+    if (valid) {
+        G = query_geo(g, qx, qy, qz);
+        rb0 = load_row_bounds(g, ((size_t)G.cz * ny + G.cy) * nx + G.cx);
+        ws->rb0[lane] = rb0;
+    }
+    SF_PH(pc, 1);
+    if (valid && rb0.s1 < rb0.s2) scan4<WINDOW, true>(g, w, rb0.s1, rb0.s2, qx, qy, qz, hit);
+    SF_PH(pc, 2);
+    if (valid) {
+#else
     if (valid) {
         const QueryGeo G = query_geo(g, qx, qy, qz);
         const RowBounds rb0 = load_row_bounds(g, ((size_t)G.cz * ny + G.cy) * nx + G.cx);
         ws->rb0[lane] = rb0;
         if (rb0.s1 < rb0.s2) scan4<WINDOW, true>(g, w, rb0.s1, rb0.s2, qx, qy, qz, hit);
+#endif
         if (rb0.s1 + 4 < rb0.s2) {
             if (hit.d2 > 0.0f) mask |= 1u << 10;
             else hit.lb2 = 0.0f; // the rest of the cell is not examined
@@ -483,8 +519,17 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    SF_PH(pc, 3);
+    SF_PHC(pc, 11, (unsigned)total);
+#ifdef SF_PHASE_TRACE
+    unsigned lane_trips = 0, lane_cands = 0;
+#endif
     for (int i0 = 0; i0 < total; i0 += 64) {
+        SF_PHC(pc, 9, 1u);
         const int idx = i0 + lane;
+#ifdef SF_PHASE_TRACE
+        unsigned my_trips = 0;
+#endif
         if (idx < total) {
             const uint32_t e = ws->task[idx];
             const int owner = (int)(e >> 4), t = (int)(e & 15u);
@@ -522,6 +567,9 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
                 h.px = h.py = h.pz = 0.0f;
                 h.lb2 = 3.0e38f;
                 scan_range<WINDOW, true>(g, w, a, b, Q.x, Q.y, Q.z, h);
+#ifdef SF_PHASE_TRACE
+                my_trips = (b - a + 3u) / 4u; lane_cands += b - a; lane_trips += my_trips;
+#endif
                 bound = fminf(bound, h.lb2);
                 const unsigned long long mine = pack_hit(h.d2, h.j);
                 if (mine != start) { // something lexicographically smaller: whichever of (the best by now, this candidate) loses is a runner-up
@@ -531,9 +579,16 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
             }
             atomicMin(&ws->lb2[owner], __float_as_uint(bound));
         }
+#ifdef SF_PHASE_TRACE
+        { unsigned m = my_trips; for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o)); SF_PHC(pc, 10, m); }
+#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    SF_PH(pc, 4);
+#ifdef SF_PHASE_TRACE
+    { unsigned m = lane_trips, c = lane_cands; for (int o = 32; o > 0; o >>= 1) { m += (unsigned)__shfl_xor((int)m, o); c += (unsigned)__shfl_xor((int)c, o); } SF_PHC(pc, 12, m); SF_PHC(pc, 13, c); }
+#endif
     bool more = false; // ring 1 did not settle this query
     if (valid) {
         const unsigned long long m = ws->best[lane];
@@ -568,6 +623,7 @@ __device__ __forceinline__ NNHit nn_search_wave(const SfGrid &g, const SfWindow 
             hit.lb2 = 0.0f; // no bound kept for the per-lane rings
         }
     }
+    SF_PH(pc, 5);
     if (!COOP) return hit;
     // COOP: queries whose best is still farther than the boundary of their 27 cells (scan points with no map point nearby:
     // new ground, moving objects, the rim of the map crop) go on ring by ring TOGETHER.  Lane by lane that is a serial walk
