@@ -1478,8 +1478,11 @@ __device__ __forceinline__ void solve_o3d(IcpState *S, const double *rec, int n_
     S->prev_rmse = rmse;
 }
 
-__device__ __forceinline__ void solve_plane(IcpState *S, const double *rec, int n_src, int K)
+// upd_out (optional, 12 doubles): the pose update this solve applied, T <- upd T (the identity when it applied none)
+__device__ __forceinline__ void solve_plane(IcpState *S, const double *rec, int n_src, int K, double *upd_out = nullptr)
 {
+    if (upd_out)
+        for (int i = 0; i < 12; ++i) upd_out[i] = (i % 5 == 0) ? 1.0 : 0.0;
     const double n = rec[0];
     S->fitness = n_src > 0 ? n / (double)n_src : 0.0;
     S->rmse = n > 0 ? sqrt(rec[29] / n) : 0.0;
@@ -1502,6 +1505,8 @@ __device__ __forceinline__ void solve_plane(IcpState *S, const double *rec, int 
     }
     double upd[16], Tc[16];
     vec6_to_mat4(x, upd);
+    if (upd_out)
+        for (int i = 0; i < 12; ++i) upd_out[i] = upd[i];
 #pragma unroll
     for (int i = 0; i < 16; ++i) Tc[i] = S->T[i];
     mat4_mul(upd, Tc, Tc);
@@ -1567,6 +1572,8 @@ struct FreezeState {
     int launch_mode;  // `mode` as the launch in flight found it (the solve's bookkeeping needs it when reduce and solve are two kernels)
     double motion0;   // IcpState::motion the freeze launch classified with
     double Tf[12];    // the pose of the freeze launch
+    double D[12];     // the pose relative to it: the product of the updates solved since (exact for ANY initial pose -- a float32 or
+                      // blended, not quite rigid prior (localization_node.cpp:329) included; T_now Tf^-1 through a rigid inverse was not)
     double mom[FZ_NMOM];
 };
 struct FreezeParams { float guard_scale, guard_min, guard_max; int max_tries; };
@@ -1870,7 +1877,7 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWin
 // full grid's speed.  grid (FZ_FEW, batch): workgroup r of every scan runs on XCD r % 8 and takes the rows = r (mod FZ_FEW).
 constexpr int FZ_FEW = 16;
 template <int Q, bool SHARD>
-__global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz_few(SfGrid g, SfWindow w, FzArgs A)
+__global__ __launch_bounds__(BLK) void k_nn_red_fz_few(SfGrid g, SfWindow w, FzArgs A)
 {
     const int r = (int)blockIdx.x, b = (int)blockIdx.y;
     if (A.st[b].done) return;
@@ -2028,31 +2035,43 @@ __device__ __forceinline__ void freeze_fold(const IcpState *S, FreezeState *F, i
     reduce_partials<NREC_PLANE, NT>(partials + (size_t)b * stride * REC_STRIDE, rows_live, rec);
     if (fmode == 1) {
         reduce_columns<FZ_NMOM, FZ_NMOM, NT>(fb.mom_part + (size_t)b * stride * FZ_NMOM, rows, mom);
-        // the rows' active lists -> one list per scan (row order, slot order inside a row): where each row's piece starts ...
+        // the rows' active lists -> one list per scan (row order, slot order inside a row).  First whether every row could list
+        // its active queries at all (a row beyond FZ_CAP: the freeze does not hold, NO list is built -- the prefix below would run
+        // past the scan's region of act_all into the next scan's list) ...
         __shared__ uint32_t pre[NT];
-        if (threadIdx.x == 0) act_worst = 0u;
+        if (threadIdx.x == 0) { act_worst = 0u; act_total = 0u; }
         __syncthreads();
-        uint32_t run = 0;
-        for (int r0 = 0; r0 < rows; r0 += NT) {
-            const int r = r0 + (int)threadIdx.x;
-            const uint32_t c = r < rows ? fb.act_cnt[(size_t)b * stride + r] : 0u;
-            pre[threadIdx.x] = c;
-            __syncthreads();
-            for (int off = 1; off < NT; off <<= 1) { // inclusive scan of the chunk
-                const uint32_t t = (int)threadIdx.x >= off ? pre[threadIdx.x - off] : 0u;
+        {
+            uint32_t worst = 0u, sum = 0u;
+            for (int r = (int)threadIdx.x; r < rows; r += NT) {
+                const uint32_t c = fb.act_cnt[(size_t)b * stride + r];
+                worst = max(worst, c);
+                sum += c;
+            }
+            if (worst > (uint32_t)FZ_CAP) atomicMax(&act_worst, worst);
+            if (sum) atomicAdd(&act_total, sum); // (integers: order independent)
+        }
+        __syncthreads();
+        if (act_worst <= (uint32_t)FZ_CAP) { // ... then where each row's piece starts, and the copy (rows * FZ_CAP entries at most: inside the scan's region)
+            uint32_t run = 0;
+            for (int r0 = 0; r0 < rows; r0 += NT) {
+                const int r = r0 + (int)threadIdx.x;
+                const uint32_t c = r < rows ? fb.act_cnt[(size_t)b * stride + r] : 0u;
+                pre[threadIdx.x] = c;
                 __syncthreads();
-                pre[threadIdx.x] += t;
+                for (int off = 1; off < NT; off <<= 1) { // inclusive scan of the chunk
+                    const uint32_t t = (int)threadIdx.x >= off ? pre[threadIdx.x - off] : 0u;
+                    __syncthreads();
+                    pre[threadIdx.x] += t;
+                    __syncthreads();
+                }
+                const uint32_t start = run + pre[threadIdx.x] - c;
+                if (r < rows && (size_t)start + c <= (size_t)stride * FZ_CAP)
+                    for (uint32_t i = 0; i < c; ++i) fb.act_all[(size_t)b * stride * FZ_CAP + start + i] = (uint32_t)r * (uint32_t)(BLK * SF_WIDE_QPL) + fb.act_ids[((size_t)b * stride + r) * FZ_CAP + i];
+                run += pre[NT - 1];
                 __syncthreads();
             }
-            const uint32_t start = run + pre[threadIdx.x] - c;
-            if (c > (uint32_t)FZ_CAP) atomicMax(&act_worst, c);
-            if (r < rows && c <= (uint32_t)FZ_CAP) // ... and the copy (a row that overflowed: the freeze does not hold, the list is not used)
-                for (uint32_t i = 0; i < c; ++i) fb.act_all[(size_t)b * stride * FZ_CAP + start + i] = (uint32_t)r * (uint32_t)(BLK * SF_WIDE_QPL) + fb.act_ids[((size_t)b * stride + r) * FZ_CAP + i];
-            run += pre[NT - 1];
-            __syncthreads();
         }
-        if (threadIdx.x == 0) act_total = run;
-        __syncthreads();
     } else if (fmode == 2) {
         if (threadIdx.x < FZ_NMOM) mom[threadIdx.x] = F->mom[threadIdx.x];
     }
@@ -2060,13 +2079,8 @@ __device__ __forceinline__ void freeze_fold(const IcpState *S, FreezeState *F, i
         if (threadIdx.x == 0) {
             if (fmode == 1) { // the freeze pose is this launch's pose: D = identity
                 for (int i = 0; i < 12; ++i) D[i] = (i % 5 == 0) ? 1.0 : 0.0;
-            } else { // D = T_now * Tf^-1 (Tf rigid: inverse = (R^T, -R^T t))
-                const double *Tf = F->Tf;
-                for (int r = 0; r < 3; ++r) {
-                    for (int c = 0; c < 3; ++c) D[4 * r + c] = S->T[4 * r] * Tf[4 * c] + S->T[4 * r + 1] * Tf[4 * c + 1] + S->T[4 * r + 2] * Tf[4 * c + 2]; // R_now R_f^T
-                    D[4 * r + 3] = 0.0;
-                }
-                for (int r = 0; r < 3; ++r) D[4 * r + 3] = S->T[4 * r + 3] - (D[4 * r] * Tf[3] + D[4 * r + 1] * Tf[7] + D[4 * r + 2] * Tf[11]);
+            } else { // the updates solved since the freeze launch (freeze_after_update): T_now = D T_f whatever T_f is
+                for (int i = 0; i < 12; ++i) D[i] = F->D[i];
             }
         }
         __syncthreads();
@@ -2083,7 +2097,7 @@ __device__ __forceinline__ void freeze_fold(const IcpState *S, FreezeState *F, i
                 F->mode = 2;
                 F->froze += 1;
                 F->motion0 = S->motion;
-                for (int i = 0; i < 12; ++i) F->Tf[i] = S->T[i];
+                for (int i = 0; i < 12; ++i) { F->Tf[i] = S->T[i]; F->D[i] = (i % 5 == 0) ? 1.0 : 0.0; }
                 for (int i = 0; i < FZ_NMOM; ++i) F->mom[i] = mom[i];
             }
         }
@@ -2092,8 +2106,16 @@ __device__ __forceinline__ void freeze_fold(const IcpState *S, FreezeState *F, i
 }
 
 // the solve half's bookkeeping, by the lane that solved (m0 / m1: IcpState::motion before / after the pose update)
-__device__ __forceinline__ void freeze_after_update(const IcpState *S, FreezeState *F, double m0, double m1, const FreezeParams &fp, int request)
+// upd: the pose update the solve has just applied (solve_plane)
+__device__ __forceinline__ void freeze_after_update(const IcpState *S, FreezeState *F, double m0, double m1, const FreezeParams &fp, int request, const double *upd)
 {
+    if (F->mode == 2) { // D <- upd D (3 x 4 affine composition, float64)
+        double Dn[12];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 4; ++c) Dn[4 * r + c] = upd[4 * r] * F->D[c] + upd[4 * r + 1] * F->D[4 + c] + upd[4 * r + 2] * F->D[8 + c] + (c == 3 ? upd[4 * r + 3] : 0.0);
+        }
+        for (int i = 0; i < 12; ++i) F->D[i] = Dn[i];
+    }
     if (F->mode == 2 && !(m1 - F->motion0 <= (double)F->guard * 0.98)) { // the next launch's pose is beyond what the frozen queries were cleared for
         F->mode = 0;
         F->tries += 1;
@@ -2123,9 +2145,10 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve_fz(IcpState *__restrict__
 #pragma unroll
         for (int i = 0; i < 12; ++i) To[i] = S->T[i];
         const double m0 = S->motion;
-        solve_plane(S, rec, n_src, K);
+        double upd[12];
+        solve_plane(S, rec, n_src, K, upd);
         track_motion(S, To, boxp[b]);
-        freeze_after_update(S, F, m0, S->motion, fp, request);
+        freeze_after_update(S, F, m0, S->motion, fp, request, upd);
     }
 }
 
@@ -2178,11 +2201,12 @@ __global__ void k_solve_only(IcpState *__restrict__ st, const double *__restrict
 #pragma unroll
     for (int i = 0; i < 12; ++i) To[i] = S->T[i];
     const double m0 = S->motion;
+    double upd[12];
     if (MODE == 1) solve_o3d(S, rec, n_src, 0, K);
-    else solve_plane(S, rec, n_src, K);
+    else solve_plane(S, rec, n_src, K, upd);
     track_motion(S, To, boxp[b]);
     if (margin > 0.0f && !S->done) own_check_motion(S, boxp[b], margin); // sharded path only (the scan's own box, computed on the device)
-    if (MODE == 2 && fz) freeze_after_update(S, fz + b, m0, S->motion, fp, request);
+    if (MODE == 2 && fz) freeze_after_update(S, fz + b, m0, S->motion, fp, request, upd);
 }
 
 // ------------------------------------------------------------------ sharded step over the P2P transport, two kernels
@@ -2272,11 +2296,12 @@ __global__ __launch_bounds__(64) void k_gather_solve(IcpState *__restrict__ st, 
 #pragma unroll
         for (int i = 0; i < 12; ++i) To[i] = S->T[i];
         const double m0 = S->motion;
+        double upd[12];
         if (MODE == 1) solve_o3d(S, rec, n_src, 0, K);
-        else solve_plane(S, rec, n_src, K);
+        else solve_plane(S, rec, n_src, K, upd);
         track_motion(S, To, boxp[b]);
         if (margin > 0.0f && !S->done) own_check_motion(S, boxp[b], margin);
-        if (MODE == 2 && fz) freeze_after_update(S, fz + b, m0, S->motion, fp, request);
+        if (MODE == 2 && fz) freeze_after_update(S, fz + b, m0, S->motion, fp, request, upd);
     }
 }
 

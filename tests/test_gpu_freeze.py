@@ -133,6 +133,46 @@ def test_outliers_and_a_scan_leaving_the_acceptance_radius(api, ctx, synth, worl
     same_result(on, off, tol=1e-10)
 
 
+def test_rows_that_overflow_next_to_rows_that_do_not(api, ctx, synth, world):
+    """One region of one scan sits right at the acceptance radius: with a guard of a few millimetres those queries are all
+    active, the slab rows that hold them overflow their lists while the rows after them do not.  The freeze of that scan must
+    be voided as a whole -- a partial list would run into the next scan's -- and the other scans of the batch, which freeze,
+    must come out as without."""
+    rng = np.random.default_rng(11)
+    scans = world["scans"].copy()
+    sel = np.nonzero(scans[1, :, 0] < np.quantile(scans[1, :, 0], 0.3))[0]        # cell order: a contiguous stretch of slab rows
+    scans[1, sel, 2] += rng.uniform(0.27, 0.33, len(sel)).astype(np.float32)       # around the 0.3 m acceptance radius below
+
+    def go(freeze):
+        icp = api.Icp(ctx, 0.3, 20, 0.05, 1e-5)
+        icp.set_target(world["mp"])
+        icp.set_query_order("cell")
+        icp.set_freeze(freeze)
+        icp.set_freeze_params(guard_scale=0.0, guard_min=5e-3, guard_max=5e-3)
+        icp.set_source_batch(scans)
+        icp.set_initial_batch(world["inits"])
+        r = icp.align_batch("p2plane")
+        s = icp.freeze_stats()
+        icp.close()
+        return r, s
+    off, _ = go(False)
+    on, stats = go(True)
+    assert stats["failed"] >= 1 and stats["froze"] >= 2, stats
+    same_result(on, off, tol=1e-10)
+
+
+def test_a_prior_that_is_not_quite_rigid(api, ctx, synth, world):
+    """sf_icp_set_initial_transformation takes float32 (orthonormal to 6e-8 only) and the node's prior is an element-wise blend
+    of two poses (localization_node.cpp:329): the frozen evaluation must hold for any initial pose, not only rigid ones."""
+    f32 = np.stack([T.astype(np.float32).astype(np.float64) for T in world["inits"]])
+    blend = np.stack([0.8 * T + 0.2 * synth.make_T((0.02, 0.01, -0.01), (0.3, 0.2, -0.5)) @ T for T in world["inits"]])
+    for inits in (f32, blend):
+        off, _ = run(api, ctx, world, False, inits=inits)
+        on, stats = run(api, ctx, world, True, inits=inits)
+        assert stats["froze"] >= 3
+        same_result(on, off)
+
+
 @pytest.mark.parametrize("margin,want_resume", [(1.0, False), (0.02, True)])
 def test_sharded_ranks_freeze_their_own_queries(api, ctx, synth, world, margin, want_resume):
     """Three x-slabs of the map held by three sf_icp objects stepping in lockstep (sf_icp_align_group: the C side's sharded loop
