@@ -134,31 +134,24 @@ def test_outliers_and_a_scan_leaving_the_acceptance_radius(api, ctx, synth, worl
 
 
 def test_rows_that_overflow_next_to_rows_that_do_not(api, ctx, synth, world):
-    """One region of one scan sits right at the acceptance radius: with a guard of a few millimetres those queries are all
-    active, the slab rows that hold them overflow their lists while the rows after them do not.  The freeze of that scan must
-    be voided as a whole -- a partial list would run into the next scan's -- and the other scans of the batch, which freeze,
-    must come out as without."""
+    """A third of one scan carries five times the noise: its neighbours are far and its runner-up bounds tight, so with a guard
+    of a few millimetres a quarter and more of those queries stay active -- the slab rows that hold them overflow their
+    lists while the rows after them do not.  The freeze of that scan must be voided as a whole (a partial list would run into
+    the next scan's) and the other scans of the batch, which freeze, must come out as without.  The guard at which exactly
+    that happens depends on the data: a few are tried, every one of them must give the launch-by-launch result, and at
+    least one must show the mixed outcome."""
     rng = np.random.default_rng(11)
     scans = world["scans"].copy()
     sel = np.nonzero(scans[1, :, 0] < np.quantile(scans[1, :, 0], 0.3))[0]        # cell order: a contiguous stretch of slab rows
-    scans[1, sel, 2] += rng.uniform(0.27, 0.33, len(sel)).astype(np.float32)       # around the 0.3 m acceptance radius below
-
-    def go(freeze):
-        icp = api.Icp(ctx, 0.3, 20, 0.05, 1e-5)
-        icp.set_target(world["mp"])
-        icp.set_query_order("cell")
-        icp.set_freeze(freeze)
-        icp.set_freeze_params(guard_scale=0.0, guard_min=5e-3, guard_max=5e-3)
-        icp.set_source_batch(scans)
-        icp.set_initial_batch(world["inits"])
-        r = icp.align_batch("p2plane")
-        s = icp.freeze_stats()
-        icp.close()
-        return r, s
-    off, _ = go(False)
-    on, stats = go(True)
-    assert stats["failed"] >= 1 and stats["froze"] >= 2, stats
-    same_result(on, off, tol=1e-10)
+    scans[1, sel] += rng.normal(0.0, 0.05, (len(sel), 3)).astype(np.float32)
+    off, _ = run(api, ctx, world, False, scans=scans)
+    mixed = []
+    for guard in (1.0e-3, 1.5e-3, 2.0e-3, 2.5e-3, 3.0e-3):
+        on, stats = run(api, ctx, world, True, scans=scans, params=dict(guard_scale=0.0, guard_min=guard, guard_max=guard))
+        same_result(on, off, tol=1e-10)
+        if stats["failed"] >= 1 and stats["froze"] >= 2:
+            mixed.append((guard, stats))
+    assert mixed, "no guard gave a scan whose lists overflow next to scans that freeze"
 
 
 def test_a_prior_that_is_not_quite_rigid(api, ctx, synth, world):

@@ -54,11 +54,14 @@ def test_tile_search_forms_the_same_pairs(api, ctx, synth, world, mode, reuse):
 
 
 def test_queries_that_leave_the_staged_region_walk_the_global_index(api, ctx, synth, world):
-    # a prior 0.45 m off: after the first pose update most queries sit more than a cell away from where they were binned
-    inits = np.stack([synth.make_T((0.45, -0.3, 0.1), (0.0, 0.0, 0.3)) for _ in range(len(world["scans"]))])
-    r0, _ = run(api, ctx, world, "p2plane", False, True, iters=8, inits=inits)
-    r1, i1 = run(api, ctx, world, "p2plane", True, True, iters=8, inits=inits)
-    assert i1["left_region"] > 0
+    # an index of 0.1 m cells: the staged halo tolerates 0.1 m of motion since the queries were binned, the scans start 0.11 m off
+    cloud = api.Cloud(ctx, world["ds"])
+    mp = api.Map(ctx, cloud, 0.1)
+    mp.estimate_normals(0.25)
+    w = dict(map=mp, scans=world["scans"])
+    r0, _ = run(api, ctx, w, "p2plane", False, True, iters=8)
+    r1, i1 = run(api, ctx, w, "p2plane", True, True, iters=8)
+    assert i1["on"] and i1["left_region"] > 0 and i1["from_lds"] > 0
     same(synth, r0, r1)
 
 
