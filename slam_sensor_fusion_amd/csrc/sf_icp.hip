@@ -1875,7 +1875,7 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWin
 // row function returning at once).  A scan that is NOT frozen (its freeze launch was voided, it thawed, or the last update
 // was still too large to ask) is walked by its FZ_FEW workgroups row by row, stride FZ_FEW: correct, at roughly 3/4 of the
 // full grid's speed.  grid (FZ_FEW, batch): workgroup r of every scan runs on XCD r % 8 and takes the rows = r (mod FZ_FEW).
-constexpr int FZ_FEW = 16;
+constexpr int FZ_FEW = 64;
 template <int Q, bool SHARD>
 __global__ __launch_bounds__(BLK) void k_nn_red_fz_few(SfGrid g, SfWindow w, FzArgs A)
 {

@@ -36,7 +36,8 @@ def main():
     scans = np.load(os.path.join(d, "scans.npy"))
     inits = np.load(os.path.join(d, "inits.npy"))
     tag = open(os.path.join(d, "tag.txt")).read().strip()
-    ctx = api.Context(0)
+    # SF_TEST_RANK_PER_DEVICE: one rank per device (tests/test_gpu_multi_device.py); default: every rank on device 0
+    ctx = api.Context(rank if os.environ.get("SF_TEST_RANK_PER_DEVICE") == "1" else 0)
     edges = sharded.slab_edges(ds[:, 0], world)
     keep = sharded.slab_select(ds, edges, rank, halo=MAX_DIST + NORMAL_RADIUS + CELL)
     mp = api.Map(ctx, api.Cloud(ctx, ds[keep]), CELL)
