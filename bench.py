@@ -78,7 +78,8 @@ def parse():
     ap.add_argument("--query-order", default="auto", choices=["auto", "as_given", "cell"], help="sf_icp_set_query_order")
     ap.add_argument("--no-nn-reuse", action="store_true", help="sf_icp_set_nn_reuse(0): search every query in every iteration")
     ap.add_argument("--no-freeze", action="store_true", help="sf_icp_set_freeze(0): every launch of an alignment streams every query (rounds 1-3 up to here)")
-    ap.add_argument("--no-tile", action="store_true", help="sf_icp_set_tile_search(0): the searching launches walk the global grid index (rounds 1-3)")
+    ap.add_argument("--tile", action="store_true", help="sf_icp_set_tile_search(always): the searching launches served out of LDS tile by tile (sf_tile.hpp; measured "
+                                                        "slower than the walk through the global grid index, which stays the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (no-reuse throughput, upload-inclusive rate, single-scan latency)")
     ap.add_argument("--no-graph", action="store_true")
@@ -203,7 +204,7 @@ def main():
         icp.set_query_order(args.query_order)
         icp.set_nn_reuse(not args.no_nn_reuse)
         icp.set_freeze(False if args.no_freeze else "auto")
-        icp.set_tile_search(False if args.no_tile else "auto")
+        icp.set_tile_search("always" if args.tile else False)
         return icp
 
     # ---------------- the registration driver of this rank
@@ -637,6 +638,18 @@ def main():
             torch.cuda.synchronize()
             extras["value_no_freeze"] = B * k / (time.perf_counter() - t1)
             icp.set_freeze("auto")
+        if args.mode != "ref_cpp" and not args.tile:
+            # the searching launches served out of LDS tile by tile (sf_tile.hpp, opt-in): the measurement round 4 was asked for
+            icp.set_tile_search("always")
+            step()
+            torch.cuda.synchronize()
+            if icp.tile_info()["on"]:
+                t1 = time.perf_counter()
+                for _ in range(k):
+                    step()
+                torch.cuda.synchronize()
+                extras["value_tile_search"] = B * k / (time.perf_counter() - t1)
+            icp.set_tile_search(False)
         # upload-inclusive: every step uploads its batch from pinned host memory.  Double buffering: the raw H2D copy of
         # batch k+1 runs on a copy stream into one of two staging buffers while batch k is registered on the compute
         # stream, which picks the staged batch up on the device (sf_icp_set_source_batch_device) once its copy event has
@@ -878,6 +891,7 @@ def main():
         "single_scan_latency_ms": extras.get("single_scan_latency_ms"),
         "value_no_reuse": extras.get("value_no_reuse"),
         "value_no_freeze": extras.get("value_no_freeze"),
+        "value_tile_search": extras.get("value_tile_search"),
         "value_upload_inclusive": extras.get("value_upload_inclusive"),
         "value_32_in_flight": extras.get("value_32_in_flight"),
         "value_stream_config4": extras.get("value_stream_config4"),

@@ -54,6 +54,7 @@ struct IcpState {
     int iterations, done, research, n_corr, n_research, flags, converged;
     int n_points; // single-scan REF_CPP with the count in device memory: the count the alignment ran on (sf_icp_source_count)
     int cache_live; // launch list, O3D_P2P / P2PLANE: the scan's neighbour-cache entries have been written since the last (re)start
+    int froze_launch; // frozen pairs: index of the launch in which the scan FIRST froze, -1 if it never did (the host's schedule learns from it)
     double T_list[12]; // sharded path: the pose this rank's owned-query arrays were built at
     double motion;     // launch list: upper bound on how far any point of the source batch has moved since the alignment began (sum over the pose updates)
 };
@@ -464,6 +465,7 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
     s.iterations = s.done = s.research = s.n_corr = s.n_research = s.flags = s.converged = 0;
     s.n_points = -1;
     s.cache_live = 0;
+    s.froze_launch = -1;
     s.motion = 0.0;
     for (int i = 0; i < 12; ++i) s.T_list[i] = s.T[i];
     st[b] = s;
@@ -1875,9 +1877,9 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz(SfGrid g, SfWin
 // row function returning at once).  A scan that is NOT frozen (its freeze launch was voided, it thawed, or the last update
 // was still too large to ask) is walked by its FZ_FEW workgroups row by row, stride FZ_FEW: correct, at roughly 3/4 of the
 // full grid's speed.  grid (FZ_FEW, batch): workgroup r of every scan runs on XCD r % 8 and takes the rows = r (mod FZ_FEW).
-constexpr int FZ_FEW = 64;
+constexpr int FZ_FEW = 16;
 template <int Q, bool SHARD>
-__global__ __launch_bounds__(BLK) void k_nn_red_fz_few(SfGrid g, SfWindow w, FzArgs A)
+__global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz_few(SfGrid g, SfWindow w, FzArgs A)
 {
     const int r = (int)blockIdx.x, b = (int)blockIdx.y;
     if (A.st[b].done) return;
@@ -2022,7 +2024,7 @@ struct FreezeBufs {
 // per scan, `rows`: the rows an ordinary launch of this scan writes.  What a rank freezes is its own business (sharded: its
 // owned queries): the record it contributes is the same sum either way.
 template <int NT>
-__device__ __forceinline__ void freeze_fold(const IcpState *S, FreezeState *F, int b, const double *__restrict__ partials, int stride, int rows, const FreezeBufs &fb, double *rec)
+__device__ __forceinline__ void freeze_fold(IcpState *S, FreezeState *F, int b, const double *__restrict__ partials, int stride, int rows, const FreezeBufs &fb, double *rec)
 {
     static_assert(NT >= FZ_NMOM && NT >= 64, "the moments are copied and contracted by the first threads");
     const int fmode = F->mode;
@@ -2096,6 +2098,7 @@ __device__ __forceinline__ void freeze_fold(const IcpState *S, FreezeState *F, i
             } else {
                 F->mode = 2;
                 F->froze += 1;
+                if (S->froze_launch < 0) S->froze_launch = S->n_research; // (this launch's index: the solve that follows counts it; a later re-freeze after a thaw does not move it)
                 F->motion0 = S->motion;
                 for (int i = 0; i < 12; ++i) { F->Tf[i] = S->T[i]; F->D[i] = (i % 5 == 0) ? 1.0 : 0.0; }
                 for (int i = 0; i < FZ_NMOM; ++i) F->mom[i] = mom[i];
@@ -2947,6 +2950,8 @@ struct sf_icp {
     int freeze = 1;                 // sf_icp_set_freeze: 0 off, 1 when the batch is large enough to gain (FREEZE_AUTO_MIN_QUERIES), 2 always
     FreezeParams fz_prm{8.0f, 2.0e-5f, 3.0e-4f, 3};
     int fz_from = 5;                // launch index of the first launch that may be a freeze launch
+    bool fz_from_auto = true;       // learnt from the last fetched alignment (sf_icp_fetch_results); sf_icp_set_freeze_params fixes it
+    int fz_fetches = 0;             // fetched alignments since fz_from was last reset to its default (every FZ_PROBE_EVERY-th starts over)
     int fz_step = 0;                // stepping paths: launches since the pass began
     sf::DevBuf fz_state, fz_part, fz_cnt, fz_ids, fz_all;
     int64_t nn_stats_used = 0;
@@ -3906,6 +3911,32 @@ extern "C" int sf_icp_set_freeze(sf_icp *icp, int on)
     return SF_OK;
 }
 
+namespace {
+// The launches between fz_from and the one in which the scans do freeze walk every query through the few-workgroup kernels
+// (k_nn_red_fz_few: 16 workgroups per scan, ~60 % of the full grid's speed) -- nothing on the metric configuration, where
+// every scan freezes at the first chance, but measured on ring scans with a 0.3 m / 1.5 degree prior (tools/city_bench.py):
+// scans froze at launch 12 and the six launches before cost more than the frozen ones saved (-8 %).  Scans that follow each
+// other converge alike, so the schedule of the NEXT alignment starts asking where this one froze: fz_from = the launch by
+// which every scan that froze had frozen, never earlier than the default; an alignment that froze nothing pushes it out of
+// reach (freeze_on), and every FZ_PROBE_EVERY-th fetched alignment starts again from the default.
+constexpr int FZ_FROM_DEFAULT = 5, FZ_PROBE_EVERY = 32;
+void freeze_learn_schedule(sf_icp *icp)
+{
+    if (!icp->fz_from_auto || icp->last_fused || icp->shard || icp->last_mode != SF_ICP_P2PLANE) return;
+    const int K = icp->prm.num_iters;
+    if (++icp->fz_fetches >= FZ_PROBE_EVERY) { icp->fz_fetches = 0; icp->fz_from = FZ_FROM_DEFAULT; return; }
+    if (!freeze_on(icp, icp->last_mode)) return; // (nothing was tried: nothing learnt)
+    int latest = -1, never = 0;
+    for (int b = 0; b < icp->batch; ++b) {
+        const IcpState &S = icp->h_state[(size_t)b];
+        if (S.froze_launch >= 0) latest = std::max(latest, S.froze_launch);
+        else if (S.iterations >= K) never += 1;
+    }
+    if (latest < 0) icp->fz_from = std::max(FZ_FROM_DEFAULT, K); // nothing froze: not worth the slower launches next time
+    else if (never * 4 <= icp->batch) icp->fz_from = std::min(std::max(FZ_FROM_DEFAULT, latest), std::max(FZ_FROM_DEFAULT, K - 2));
+}
+} // namespace
+
 extern "C" int sf_icp_set_freeze_params(sf_icp *icp, float guard_scale, float guard_min, float guard_max, int max_tries, int from_launch)
 {
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
@@ -3913,6 +3944,7 @@ extern "C" int sf_icp_set_freeze_params(sf_icp *icp, float guard_scale, float gu
              "bad freeze parameters");
     icp->fz_prm = FreezeParams{guard_scale, guard_min, guard_max, max_tries};
     icp->fz_from = from_launch;
+    icp->fz_from_auto = false;
     return SF_OK;
 }
 
@@ -4074,6 +4106,7 @@ extern "C" int sf_icp_fetch_results(sf_icp *icp, sf_icp_result *out)
     if (icp->profiling) prof_collect(icp);
     SF_TRY(check_barrier_flags(icp));
     for (int b = 0; b < icp->batch; ++b) fill_result(icp, icp->last_mode, icp->h_state[(size_t)b], &icp->inits[(size_t)b * 16], out + b);
+    freeze_learn_schedule(icp);
     return SF_OK;
 }
 
