@@ -13,10 +13,12 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <cerrno>
 #include <chrono>
+#include <ctime>
 
 #include <algorithm>
 #include <cmath>
@@ -104,10 +106,27 @@ struct P2pHandle { // SF_COMM_P2P_HANDLE_BYTES: what the launcher hands round
     int64_t max_count;
     uint64_t region_bytes;
     uint64_t ptr; // same-process peers (several contexts in one process) use the pointer itself
+    uint64_t nonce; // drawn once per process: a pid alone does not tell processes of different pid namespaces (containers: both often pid 1) apart
     hipIpcMemHandle_t ipc;
-    char pad[128 - 48 - sizeof(hipIpcMemHandle_t)];
+    char pad[128 - 56 - sizeof(hipIpcMemHandle_t)];
 };
 static_assert(sizeof(P2pHandle) == SF_COMM_P2P_HANDLE_BYTES, "handle blob size");
+
+// what tells this process from every other on the node, whatever their pid namespaces
+static uint64_t process_nonce()
+{
+    static const uint64_t nonce = [] {
+        uint64_t v = 0;
+        const int fd = open("/dev/urandom", O_RDONLY);
+        if (fd >= 0) {
+            if (read(fd, &v, sizeof(v)) != (ssize_t)sizeof(v)) v = 0;
+            close(fd);
+        }
+        if (v == 0) v = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull ^ (uint64_t)getpid() ^ (uint64_t)(uintptr_t)&v;
+        return v | 1ull;
+    }();
+    return nonce;
+}
 
 // status word (pinned host memory): 0 ok, 1 timed out waiting for a peer, 2 aborted by a peer / the host.
 // grid.x = chunks of P2P_CHUNK doubles; a workgroup carries its chunk through publish / signal / wait / sum on its own flags
@@ -306,6 +325,7 @@ extern "C" int sf_comm_p2p_handle(sf_comm *c, void *handle)
     h.nranks = c->nranks;
     h.device = c->ctx->device;
     h.pid = (int64_t)getpid();
+    h.nonce = process_nonce();
     h.max_count = c->max_count;
     h.region_bytes = c->region_bytes;
     h.ptr = (uint64_t)(uintptr_t)c->region;
@@ -327,7 +347,7 @@ extern "C" int sf_comm_p2p_connect(sf_comm *c, const void *handles)
         SF_CHECK(h.magic == P2P_MAGIC && h.rank == r && h.nranks == c->nranks && h.max_count == c->max_count && h.region_bytes == c->region_bytes, SF_ERR_INVALID,
                  "handle %d does not describe rank %d of this communicator (ranks %d, capacity %lld)", r, r, c->nranks, (long long)c->max_count);
         if (r == c->rank) continue;
-        if (h.pid == (int64_t)getpid()) { // several ranks inside one process: the pointer is valid as it is
+        if (h.pid == (int64_t)getpid() && h.nonce == process_nonce()) { // several ranks inside one process: the pointer is valid as it is
             if (h.device != c->ctx->device) {
                 hipError_t e = hipDeviceEnablePeerAccess(h.device, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) SF_HIP(e);
@@ -358,8 +378,26 @@ extern "C" int sf_comm_p2p_rendezvous(sf_comm *c, const char *name, double timeo
     if (c->nranks == 1) return SF_OK;
     struct Board { uint32_t posted[P2P_MAX_RANKS]; uint32_t done[P2P_MAX_RANKS]; P2pHandle blob[P2P_MAX_RANKS]; };
     std::string path = name[0] == '/' ? std::string(name) : "/" + std::string(name);
-    const int fd = shm_open(path.c_str(), O_CREAT | O_RDWR, 0600);
-    SF_CHECK(fd >= 0, SF_ERR_STATE, "shm_open(%s): %s", path.c_str(), std::strerror(errno));
+    // An object of this name left behind by a run that died (its rank 0 never unlinked it) would show posted[] = 1 with blobs
+    // that pass every check.  The rank that CREATES the object (O_EXCL) is the only one that may find it fresh by
+    // construction; a rank that finds it existing accepts it only while it is young -- every rank of a live rendezvous
+    // arrives within the time limit of the first -- and otherwise removes it and starts over.
+    int fd = -1;
+    for (int attempt = 0; attempt < 4 && fd < 0; ++attempt) {
+        fd = shm_open(path.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0) break;
+        SF_CHECK(errno == EEXIST, SF_ERR_STATE, "shm_open(%s): %s", path.c_str(), std::strerror(errno));
+        fd = shm_open(path.c_str(), O_RDWR, 0600);
+        if (fd < 0) continue; // removed in between (a peer's rank 0 has finished, or it cleared a stale one): try to create again
+        struct stat sb;
+        const double limit = std::max(2.0 * timeout_s, 30.0);
+        if (fstat(fd, &sb) == 0 && std::difftime(std::time(nullptr), sb.st_mtime) > limit) {
+            close(fd);
+            fd = -1;
+            shm_unlink(path.c_str());
+        }
+    }
+    SF_CHECK(fd >= 0, SF_ERR_STATE, "shm_open(%s): could not create or join the rendezvous object", path.c_str());
     if (ftruncate(fd, (off_t)sizeof(Board)) != 0) { // a fresh object is zero-filled; growing an existing one to the same size changes nothing
         const int err = errno;
         close(fd);

@@ -182,13 +182,17 @@ class RoutedRegistration:
             self.mine[(a, e)] = (icp, comm, ids)
             for b in ids:
                 pts = scans[b][np.isfinite(scans[b]).all(1)].astype(np.float64)
-                self.boxes[b] = (pts.min(0), pts.max(0))
+                # a scan without a finite point: an empty box at the origin, as k_scan_boxes_final gives it on the device
+                # (every rank must take the same path into the collective; check_reach skips such a scan)
+                self.boxes[b] = (pts.min(0), pts.max(0)) if len(pts) else None
         return self.groups
 
     def check_reach(self, a, e, ids, results):
         """Every scan of group (a, e) must end inside the x-range its ranks cover (see the class docstring)."""
         x_lo, x_hi = self.edges[a] - self.slack, self.edges[e + 1] + self.slack
         for b, r in zip(ids, results):
+            if self.boxes[b] is None:
+                continue
             x0, x1 = box_x_range(self.boxes[b], np.asarray(r["T64"], dtype=np.float64).reshape(4, 4))
             if x0 < x_lo or x1 >= x_hi:
                 raise ScanLeftItsSlabs("scan %d was routed to slabs %d..%d (x in [%g, %g) with slack) but its registration ends at x in [%g, %g]: "
