@@ -774,6 +774,56 @@ def main():
         flow = None
         sctx.synchronize()
 
+        # a sensor-shaped workload beside the metric's uniform-random one (tools/city_bench.py is the full version, profiles/r04_city_bench*):
+        # ring scans of a synthetic city against its surface map, every scan from its own pose with its own prior error
+        if args.mode == "p2plane":
+            c_ext, c_rings, c_scans = 120.0, 128, 16
+            boxes = synth.make_city(c_ext, 30)
+            ccloud = api.Cloud(sctx, synth.sample_city(boxes, c_ext, 2_500_000))
+            ccloud.voxel_downsample(0.1, "pcl")
+            cmap = api.Map(sctx, ccloud, args.cell)
+            cmap.estimate_normals(normal_radius)
+            crng = np.random.default_rng(77)
+            truths_, cscans = [], []
+            while len(cscans) < c_scans:
+                xy = crng.uniform(-8.0, 8.0, 2)
+                T_ = synth.make_T((xy[0], xy[1], 1.8), (0.0, 0.0, crng.uniform(0, 360)))
+                s_ = synth.raycast_scan(boxes, T_, rings=c_rings, max_range=55.0, seed=synth.CITY_SEED + 10 + len(cscans) + len(truths_))
+                truths_.append(T_)
+                if len(s_) >= 0.4 * c_rings * 2032:
+                    cscans.append((T_, s_))
+            n_c = min(len(s_) for _, s_ in cscans)
+            cs = np.stack([s_[crng.choice(len(s_), n_c, replace=False)] for _, s_ in cscans])
+            cin = np.stack([T_ @ synth.make_T(crng.normal(0, 0.06, 3), crng.normal(0, 0.3, 3)) for T_, _ in cscans])
+            cicp = api.Icp(sctx, max_dist, iters, 0.05, 1e-5)
+            cicp.set_target(cmap)
+            cicp.use_graph(not args.no_graph)
+            cicp.set_source_batch(cs)
+            cicp.set_initial_batch(cin)
+            cres = cicp.align_batch("p2plane")            # (the freeze schedule is learnt from this one)
+            cicp.align_batch("p2plane")
+            t1 = time.perf_counter()
+            for _ in range(5):
+                cicp.align_batch_async("p2plane")
+            sctx.synchronize()
+            v_on = c_scans * 5 / (time.perf_counter() - t1)
+            fs_ = cicp.freeze_stats()
+            cicp.set_freeze(False)
+            cicp.align_batch("p2plane")
+            t1 = time.perf_counter()
+            for _ in range(5):
+                cicp.align_batch_async("p2plane")
+            sctx.synchronize()
+            v_off = c_scans * 5 / (time.perf_counter() - t1)
+            extras["value_city"] = {
+                "value": v_on, "value_no_freeze": v_off, "unit": "scans/s", "scans_in_flight": c_scans, "points_per_scan": int(n_c), "map_points": int(len(cmap)),
+                "froze": int(fs_["froze"]), "thawed": int(fs_["thawed"]), "voided": int(fs_["failed"]), "active_share": fs_["active_queries"] / float(n_c * c_scans),
+                "median_translation_err_vs_truth_m": float(np.median([synth.pose_error(r_["T64"], T_)[0] for r_, (T_, _) in zip(cres, cscans)])),
+                "what": "ring scans (%d x 2032 rays, 55 m range) of a %d m synthetic city vs its surface map (voxel 0.1 m), %d in flight, every scan from its own pose with a "
+                        "0.06 m / 0.3 deg prior error (1 sigma per axis), 20 point-to-plane iterations; scans this size freeze (above 131 072 points), a 64-ring scan would not -- "
+                        "profiles/r04_city_bench*.jsonl hold 64 in flight against the 8.3 M-point city, both sensors, and a 0.3 m / 1.5 deg prior" % (c_rings, int(c_ext), c_scans)}
+            cicp.close()
+
     # ---------------- roofline of the dominant kernel
     # achieved = bytes the memory system moves per launch / launch duration: from the rocprofv3 PMC passes of this same
     # command committed under profiles/ (request counts x request sizes, the gfx950 FETCH_SIZE x2 correction made explicit)
@@ -810,11 +860,11 @@ def main():
             if not (world == 1 and c["batch"] == B and c["scan_points"] == n_scan and c["map_points"] == args.map_points and c["iters"] == iters and c["mode"] == args.mode):
                 return None, "profiles/%s is for another configuration" % name
             return tj, None
-        tj, traffic_note = load_traffic("r03_traffic.json" if not args.no_nn_reuse else "r03_search_traffic.json")
+        tj, traffic_note = load_traffic("r04_traffic.json" if not args.no_nn_reuse else "r04_search_traffic.json")
         if tj is not None and tj["config"].get("nn_reuse", True) == (not args.no_nn_reuse):
             traffic = tj["traffic_bytes_per_launch"]
             traffic_src = "profiles/%s (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ by request size, separate passes; source hash %s matches this build)" % (
-                "r03_traffic.json" if not args.no_nn_reuse else "r03_search_traffic.json", src_hash)
+                "r04_traffic.json" if not args.no_nn_reuse else "r04_search_traffic.json", src_hash)
             valu = tj.get("valu")
         bytes_launch = traffic if traffic is not None else float(comp[sel_k].mean())
         achieved = bytes_launch / (nn_ms * 1e-3) / 1e9 if nn_ms > 0 else 0.0
@@ -851,11 +901,11 @@ def main():
             roof["valu_issue"] = valu
         # the searching phase under its own name: counters of the same command with `--no-nn-reuse` (every query searches in every
         # launch), taken on this build of the kernel; and the verifying phase from this run's own launch times and its compulsory stream
-        sj, _why = load_traffic("r03_search_traffic.json") if not args.no_nn_reuse else (None, None)
+        sj, _why = load_traffic("r04_search_traffic.json") if not args.no_nn_reuse else (None, None)
         if sj is not None and sj.get("avg_launch_ns_kernel_trace"):
             roof["searching_frac"] = {"frac": sj["frac_of_hbm_peak_kernel_trace"], "traffic_bytes_per_launch": sj["traffic_bytes_per_launch"],
                                       "avg_launch_us": sj["avg_launch_ns_kernel_trace"] * 1e-3, "valu_busy_frac": (sj.get("valu") or {}).get("valu_busy_frac"),
-                                      "source": "profiles/r03_search_traffic.json: PMC traffic / rocprofv3 kernel-trace duration of launches in which every query searches"}
+                                      "source": "profiles/r04_search_traffic.json: PMC traffic / rocprofv3 kernel-trace duration of launches in which every query searches"}
         sel_vk = sel_v & sel_k
         if sel_vk.any() and args.mode == "p2plane":   # (the other modes converge early: their later launches return at once)
             roof["verifying_frac"] = float(comp[sel_vk].mean() / (prof["ms"][sel_vk].mean() * 1e-3) / 1e9 / HBM_PEAK_GBS)
@@ -892,6 +942,7 @@ def main():
         "value_no_reuse": extras.get("value_no_reuse"),
         "value_no_freeze": extras.get("value_no_freeze"),
         "value_tile_search": extras.get("value_tile_search"),
+        "value_city": extras.get("value_city"),
         "value_upload_inclusive": extras.get("value_upload_inclusive"),
         "value_32_in_flight": extras.get("value_32_in_flight"),
         "value_stream_config4": extras.get("value_stream_config4"),

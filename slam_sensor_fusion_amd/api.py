@@ -102,7 +102,7 @@ def kernel_source_hash():
     carry the hash of the build their counters were taken on; bench.py only quotes them while it still matches."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("sf_icp.hip", "sf_nn.hpp", "sf_order.hpp", "sf_common.hpp"):
+    for name in ("sf_icp.hip", "sf_nn.hpp", "sf_tile.hpp", "sf_order.hpp", "sf_common.hpp"):
         with open(os.path.join(_HERE, "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
