@@ -166,6 +166,24 @@ def test_a_prior_that_is_not_quite_rigid(api, ctx, synth, world):
         same_result(on, off)
 
 
+def test_a_map_a_kilometre_from_the_origin(api, ctx, orc, synth, world):
+    """The moments are taken in un-centred map coordinates: sum r^2 and J^T r are differences of O(N |y|^2) terms, so digits
+    go like |y|^2.  Measured with the map 1 km out (1.1 km from the origin): poses still agree with the launch-by-launch
+    evaluation to 4e-12 m, the reported rmse to 3e-8 -- pinned here one order above."""
+    off = np.array([1000.0, -500.0, 0.0])
+    dsm = (world["map"] + off.astype(np.float32)).astype(np.float32)
+    mp = api.Map(ctx, api.Cloud(ctx, dsm), 0.25)
+    mp.estimate_normals(0.25)
+    w = dict(world, mp=mp)
+    inits = np.stack([synth.make_T(off, (0, 0, 0)) @ T for T in world["inits"]])
+    off_, _ = run(api, ctx, w, False, inits=inits)
+    on_, stats = run(api, ctx, w, True, inits=inits)
+    assert stats["froze"] >= 3
+    for a, b in zip(on_, off_):
+        assert a["iterations"] == b["iterations"] and a["n_corr"] == b["n_corr"]
+        assert np.abs(a["T64"] - b["T64"]).max() < 5e-11 and abs(a["rmse"] - b["rmse"]) < 5e-7
+
+
 @pytest.mark.parametrize("margin,want_resume", [(1.0, False), (0.02, True)])
 def test_sharded_ranks_freeze_their_own_queries(api, ctx, synth, world, margin, want_resume):
     """Three x-slabs of the map held by three sf_icp objects stepping in lockstep (sf_icp_align_group: the C side's sharded loop
