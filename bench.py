@@ -11,8 +11,10 @@ whole ICP with scans and map already resident in HBM.  `--mode`:
 
 What the p2plane line quotes: `value` with the library's defaults -- exact NN result in every iteration, neighbour reuse on (a
 query whose neighbour provably cannot have changed skips its search) and frozen pairs on (once a scan's pairs are certified to
-stay, their sums are evaluated from moments instead of streaming the scan; same pairs, float64 sums equal to rounding).  Measured
-beside it in the same run: `value_no_freeze` (frozen pairs off), `value_no_reuse` (every query searches in every iteration),
+stay, their sums are evaluated from moments instead of streaming the scan; same pairs, float64 sums equal to rounding), and with the
+steps of the timed loop -- enqueued back to back without a host synchronisation, as the contract's loop does -- overlapping on the library's
+two internal lanes (sf_icp_set_pipeline: a step's last, nearly idle launches run under the next step's first).  Measured
+beside it in the same run: `value_no_pipeline` (one lane), `value_no_freeze` (frozen pairs off), `value_no_reuse` (every query searches in every iteration),
 `value_32_in_flight`, `value_upload_inclusive`, `single_scan_latency_ms`, `value_stream_config4`.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
@@ -80,6 +82,7 @@ def parse():
     ap.add_argument("--no-freeze", action="store_true", help="sf_icp_set_freeze(0): every launch of an alignment streams every query (rounds 1-3 up to here)")
     ap.add_argument("--tile", action="store_true", help="sf_icp_set_tile_search(always): the searching launches served out of LDS tile by tile (sf_tile.hpp; measured "
                                                         "slower than the walk through the global grid index, which stays the default)")
+    ap.add_argument("--no-pipeline", action="store_true", help="sf_icp_set_pipeline(0): consecutive steps do not overlap (every alignment on the context's stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (no-reuse throughput, upload-inclusive rate, single-scan latency)")
     ap.add_argument("--no-graph", action="store_true")
@@ -205,6 +208,7 @@ def main():
         icp.set_nn_reuse(not args.no_nn_reuse)
         icp.set_freeze(False if args.no_freeze else "auto")
         icp.set_tile_search("always" if args.tile else False)
+        icp.set_pipeline(not args.no_pipeline)
         return icp
 
     # ---------------- the registration driver of this rank
@@ -638,6 +642,16 @@ def main():
             torch.cuda.synchronize()
             extras["value_no_freeze"] = B * k / (time.perf_counter() - t1)
             icp.set_freeze("auto")
+        # consecutive steps on one lane (sf_icp_set_pipeline(0)): every alignment on the context's stream, as up to round 3
+        icp.set_pipeline(False)
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        extras["value_no_pipeline"] = B * k / (time.perf_counter() - t1)
+        icp.set_pipeline(True)
         if args.mode != "ref_cpp" and not args.tile:
             # the searching launches served out of LDS tile by tile (sf_tile.hpp, opt-in): the measurement round 4 was asked for
             icp.set_tile_search("always")
@@ -941,6 +955,7 @@ def main():
         "single_scan_latency_ms": extras.get("single_scan_latency_ms"),
         "value_no_reuse": extras.get("value_no_reuse"),
         "value_no_freeze": extras.get("value_no_freeze"),
+        "value_no_pipeline": extras.get("value_no_pipeline"),
         "value_tile_search": extras.get("value_tile_search"),
         "value_city": extras.get("value_city"),
         "value_upload_inclusive": extras.get("value_upload_inclusive"),

@@ -544,6 +544,10 @@ class Icp:
         code = {False: 0, "off": 0, "auto": 1, True: 2, "always": 2}[on]
         _check(self.lib.sf_icp_set_freeze(self.h, C.c_int(code)))
 
+    def set_pipeline(self, on=True):
+        """Overlap of consecutive align_batch_async calls on unchanged inputs (sf_icp_set_pipeline, default on)."""
+        _check(self.lib.sf_icp_set_pipeline(self.h, C.c_int(int(bool(on)))))
+
     def set_tile_search(self, on="auto"):
         """Tile search (sf_icp_set_tile_search): the searching launches of large batches served out of LDS tile by tile, see
         include/slamfusion.h.  False / "off", "auto" (default: batches of at least 2 M queries), True / "always"."""

@@ -2936,6 +2936,29 @@ struct sf_icp {
                    map_generation == o.map_generation && epochs == o.epochs && max_corr == o.max_corr && accept == o.accept && eps == o.eps;
         }
     } graph_key;
+    // Consecutive asynchronous alignments of the launch list overlap: an alignment's last launches (frozen pairs: fourteen 16 us
+    // kernels on an otherwise idle device) run under the next one's searching launches.  Two LANES take turns; each has its own
+    // stream and its own copy of everything an alignment writes (`other` holds the lane that is not in the members of this struct).
+    // Ordering (align_lane_begin / _end): a lane starts after the context's stream as it stood when the inputs -- source, initial poses,
+    // target -- last changed, and the context's stream waits for every alignment right after it is enqueued, so whatever the caller
+    // enqueues next (a fetch, an upload, a map rebuild) is ordered behind it as before; only back-to-back alignments of unchanged
+    // inputs run side by side.  Same kernels, same data, same results (tests/test_gpu_pipeline.py).
+    struct Lane {
+        sf::DevBuf X, qcache, Xq, qkeys, qkeys2, qidx, qidx2, corr, state, d_inits, partials, fz_state, fz_part, fz_cnt, fz_ids, fz_all, qtkey, tseg, tile_stats;
+        hipGraphExec_t graph_exec = nullptr;
+        GraphKey graph_key;
+        std::vector<double> inits_uploaded;
+        uint32_t d_inits_epoch = 0xffffffffu;
+    } other;
+    int lane = 0;                 // the lane the members hold
+    int pipeline = 1;             // sf_icp_set_pipeline: 0 = every alignment on the context's stream
+    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    hipEvent_t lane_done[2] = {nullptr, nullptr}, main_mark = nullptr;
+    bool mark_valid = false;      // main_mark stands for the inputs as described by the fields below
+    uint64_t src_version = 0, mark_src_version = 0, mark_map_generation = 0;
+    const void *mark_map = nullptr;
+    SfWindow mark_window{};
+    std::vector<double> mark_inits;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> ev;
@@ -3200,6 +3223,7 @@ int icp_set_source_device_aos(sf_icp *icp, const float *d_aos, int64_t n, int ba
                        soa(icp->X0, icp->plane, 2), (int)n, icp->d_box_parts.as<ScanBox>());
     hipLaunchKernelGGL(k_scan_boxes_final, dim3(nblk(std::max(batch, 1), 64)), dim3(64), 0, icp->ctx->stream, icp->d_box_parts.as<ScanBox>(), std::max(batch, 1), icp->d_boxes.as<ScanBox>());
     icp->have_source = true;
+    icp->src_version += 1;
     return SF_OK;
 }
 
@@ -3726,6 +3750,12 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     (void)e;
     fused_release(icp);
     if (icp->graph_exec) { e = hipGraphExecDestroy(icp->graph_exec); (void)e; }
+    if (icp->other.graph_exec) { e = hipGraphExecDestroy(icp->other.graph_exec); (void)e; }
+    for (int l = 0; l < 2; ++l) {
+        if (icp->lane_stream[l]) { e = hipStreamSynchronize(icp->lane_stream[l]); (void)e; e = hipStreamDestroy(icp->lane_stream[l]); (void)e; }
+        if (icp->lane_done[l]) { e = hipEventDestroy(icp->lane_done[l]); (void)e; }
+    }
+    if (icp->main_mark) { e = hipEventDestroy(icp->main_mark); (void)e; }
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
     if (icp->inits_ev) { e = hipEventDestroy(icp->inits_ev); (void)e; }
     if (icp->h_inits) { e = hipHostFree(icp->h_inits); (void)e; }
@@ -3826,6 +3856,7 @@ extern "C" int sf_icp_set_source_scan(sf_icp *icp, sf_cloud *raw, int stride, co
     SF_HIP(hipGetLastError());
     icp->n_on_device = true;
     icp->have_source = true;
+    icp->src_version += 1;
     return SF_OK;
 }
 
@@ -3876,6 +3907,13 @@ extern "C" int sf_icp_set_nn_reuse(sf_icp *icp, int on)
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
     icp->reuse = on != 0;
     if (icp->graph_exec) { hipError_t e = hipGraphExecDestroy(icp->graph_exec); (void)e; icp->graph_exec = nullptr; } // the captured launches carry the cache pointers
+    return SF_OK;
+}
+
+extern "C" int sf_icp_set_pipeline(sf_icp *icp, int on)
+{
+    SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
+    icp->pipeline = on != 0;
     return SF_OK;
 }
 
@@ -4036,15 +4074,96 @@ extern "C" int sf_icp_use_graph(sf_icp *icp, int on)
     return SF_OK;
 }
 
+namespace {
+void raw_swap(sf::DevBuf &a, sf::DevBuf &b) // the allocations change places, epochs included (a captured graph keeps pointing at ITS lane's buffers)
+{
+    std::swap(a.p, b.p);
+    std::swap(a.cap, b.cap);
+    std::swap(a.epoch, b.epoch);
+}
+
+void lane_flip(sf_icp *icp)
+{
+    sf_icp::Lane &o = icp->other;
+    raw_swap(icp->X, o.X); raw_swap(icp->qcache, o.qcache); raw_swap(icp->Xq, o.Xq); raw_swap(icp->qkeys, o.qkeys); raw_swap(icp->qkeys2, o.qkeys2);
+    raw_swap(icp->qidx, o.qidx); raw_swap(icp->qidx2, o.qidx2); raw_swap(icp->corr, o.corr); raw_swap(icp->state, o.state); raw_swap(icp->d_inits, o.d_inits);
+    raw_swap(icp->partials, o.partials); raw_swap(icp->fz_state, o.fz_state); raw_swap(icp->fz_part, o.fz_part); raw_swap(icp->fz_cnt, o.fz_cnt);
+    raw_swap(icp->fz_ids, o.fz_ids); raw_swap(icp->fz_all, o.fz_all); raw_swap(icp->qtkey, o.qtkey); raw_swap(icp->tseg, o.tseg); raw_swap(icp->tile_stats, o.tile_stats);
+    std::swap(icp->graph_exec, o.graph_exec);
+    std::swap(icp->graph_key, o.graph_key);
+    std::swap(icp->inits_uploaded, o.inits_uploaded);
+    std::swap(icp->d_inits_epoch, o.d_inits_epoch);
+    icp->lane ^= 1;
+}
+
+// what icp_alloc sizes for the lane in the members, for the lane that has just been flipped in
+int lane_reserve(sf_icp *icp)
+{
+    const int batch = std::max(icp->batch, 1);
+    SF_TRY(icp->state.reserve(sizeof(IcpState) * (size_t)batch));
+    SF_TRY(icp->d_inits.reserve(sizeof(double) * 16 * (size_t)batch));
+    SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)REC_STRIDE * (size_t)std::max(icp->nblocks, 1) * (size_t)batch));
+    return SF_OK;
+}
+
+// RAII around the enqueue of one alignment: on a lane (piped) the context's stream is the lane's for the duration
+struct LaneScope {
+    sf_icp *icp;
+    hipStream_t main = nullptr;
+    bool piped = false;
+    int rc = SF_OK;
+    LaneScope(sf_icp *i, int mode, bool want) : icp(i)
+    {
+        if (!want) return;
+        main = icp->ctx->stream;
+        for (int l = 0; l < 2; ++l) {
+            if (!icp->lane_stream[l] && hipStreamCreateWithFlags(&icp->lane_stream[l], hipStreamNonBlocking) != hipSuccess) { rc = SF_ERR_HIP; return; }
+            if (!icp->lane_done[l] && hipEventCreateWithFlags(&icp->lane_done[l], hipEventDisableTiming) != hipSuccess) { rc = SF_ERR_HIP; return; }
+        }
+        if (!icp->main_mark && hipEventCreateWithFlags(&icp->main_mark, hipEventDisableTiming) != hipSuccess) { rc = SF_ERR_HIP; return; }
+        lane_flip(icp); // take turns
+        rc = lane_reserve(icp);
+        if (rc != SF_OK) return;
+        const sf_map *m = icp->map;
+        const bool same = icp->mark_valid && icp->mark_src_version == icp->src_version && icp->mark_map == (const void *)m && icp->mark_map_generation == m->generation &&
+                          std::memcmp(&icp->mark_window, &m->window, sizeof(SfWindow)) == 0 && icp->mark_inits == icp->inits;
+        if (!same) { // the inputs changed since the mark: everything the context's stream holds up to here comes first
+            if (hipEventRecord(icp->main_mark, main) != hipSuccess) { rc = SF_ERR_HIP; return; }
+            icp->mark_valid = true;
+            icp->mark_src_version = icp->src_version;
+            icp->mark_map = (const void *)m;
+            icp->mark_map_generation = m->generation;
+            icp->mark_window = m->window;
+            icp->mark_inits = icp->inits;
+        }
+        if (hipStreamWaitEvent(icp->lane_stream[icp->lane], icp->main_mark, 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
+        icp->ctx->stream = icp->lane_stream[icp->lane];
+        piped = true;
+        (void)mode;
+    }
+    ~LaneScope()
+    {
+        if (!piped) return;
+        hipStream_t ls = icp->ctx->stream;
+        icp->ctx->stream = main;
+        // whatever the caller enqueues next on the context's stream is ordered behind this alignment
+        if (hipEventRecord(icp->lane_done[icp->lane], ls) == hipSuccess) { hipError_t e = hipStreamWaitEvent(main, icp->lane_done[icp->lane], 0); (void)e; }
+    }
+};
+} // namespace
+
 extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
 {
     SF_TRY(check_ready(icp, mode));
     SF_CHECK(!icp->shard, SF_ERR_STATE, "a sharded alignment needs the exchange between its halves: use sf_icp_step_begin / sf_icp_step_end");
     SF_HIP(hipSetDevice(icp->ctx->device));
-    hipStream_t s = icp->ctx->stream;
     icp->last_mode = mode;
-    SF_TRY(launch_state_init(icp));
     icp->last_fused = fused_eligible(icp, mode);
+    // the launch list of a batch takes a lane (see sf_icp::Lane); the single launch, profiled runs and a count left on the device stay on the context's stream
+    LaneScope lanes(icp, mode, icp->pipeline != 0 && !icp->last_fused && !icp->profiling && !icp->n_on_device && icp->batch > 1);
+    SF_TRY(lanes.rc);
+    hipStream_t s = icp->ctx->stream;
+    SF_TRY(launch_state_init(icp));
     if (icp->last_fused) { // everything resident at once: the whole alignment is one launch (window and count by value)
         SF_TRY(order_queries(icp, mode));
         return launch_fused(icp, mode);
