@@ -5,7 +5,7 @@ set -e
 L=${1:-x}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 W=/tmp/abv_$L; mkdir -p $W gpurun_out/abv
-CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-extras $*"
+CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-extras --no-pipeline $*"
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $W/sq -o t --output-format csv -- $CMD > /dev/null 2>&1
 python3 tools/summarize_prof.py $W/sq gpurun_out/abv/${L}_sq > /dev/null
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $W/tm -o t --output-format csv -- $CMD > /dev/null 2>&1

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT="$GRAFT_REPO_ROOT/gpurun_out/profiles_$P"
 W=/tmp/prof_$P
 mkdir -p "$OUT" "$W"
-CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-extras $EXTRA"
+CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-extras --no-pipeline $EXTRA"   # (one lane: kernels traced one at a time, not two alignments side by side)
 run() { # name, rocprofv3 args...
     local name=$1; shift
     timeout -k 10 200 rocprofv3 "$@" -d "$W/$name" -o t --output-format csv -- $CMD > "$OUT/$name.log" 2>&1

@@ -7,7 +7,7 @@ cp $L /tmp/orig.so
 for lib in "$@"; do
   cp $lib $L
   rm -rf /tmp/sq_$$
-  timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d /tmp/sq_$$ -o t --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-extras $BENCH_EXTRA > /dev/null 2>&1
+  timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d /tmp/sq_$$ -o t --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-extras --no-pipeline $BENCH_EXTRA > /dev/null 2>&1
   python3 tools/summarize_prof.py /tmp/sq_$$ /tmp/sq_$$/sum
   python3 - <<PY
 import json
