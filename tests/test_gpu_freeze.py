@@ -166,6 +166,37 @@ def test_a_prior_that_is_not_quite_rigid(api, ctx, synth, world):
         same_result(on, off)
 
 
+def test_the_schedule_learnt_from_the_last_alignment_changes_no_result(api, ctx, synth, world):
+    """sf_icp_fetch_results moves the launch at which the NEXT alignment starts asking for a freeze to where this one's scans first
+    froze (freeze_learn_schedule): priors 0.08 m / 0.5 degrees off converge a few launches later, so the second alignment of the same object runs
+    another launch list -- with the same pairs and, to summation rounding, the same poses as the first and as no freezing at all;
+    sf_icp_set_freeze_params pins the launch and switches the learning off."""
+    rng = np.random.default_rng(21)
+    inits = np.stack([synth.make_T(rng.normal(0, 0.08, 3), rng.normal(0, 0.5, 3)) @ T for T in world["inits"]])
+    off, _ = run(api, ctx, world, False, inits=inits, iters=25)
+    icp = api.Icp(ctx, 0.5, 25, 0.05, 1e-5)
+    icp.set_target(world["mp"])
+    icp.set_query_order("cell")
+    icp.set_freeze(True)
+    icp.set_source_batch(world["scans"])
+    icp.set_initial_batch(inits)
+    first = icp.align_batch("p2plane")
+    s1 = icp.freeze_stats()
+    second = icp.align_batch("p2plane")
+    s2 = icp.freeze_stats()
+    third = icp.align_batch("p2plane")
+    assert s1["froze"] >= 3 and s2["froze"] >= 3
+    same_result(first, off, tol=1e-10)
+    same_result(second, off, tol=1e-10)
+    bitwise(second, third)                    # the schedule has settled
+    icp.set_freeze_params(from_launch=5)      # explicit: the default launch again, and it stays
+    fourth = icp.align_batch("p2plane")
+    bitwise(fourth, first)
+    fifth = icp.align_batch("p2plane")
+    bitwise(fifth, first)
+    icp.close()
+
+
 def test_a_map_a_kilometre_from_the_origin(api, ctx, orc, synth, world):
     """The moments are taken in un-centred map coordinates: sum r^2 and J^T r are differences of O(N |y|^2) terms, so digits
     go like |y|^2.  Measured with the map 1 km out (1.1 km from the origin): poses still agree with the launch-by-launch
