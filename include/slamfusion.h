@@ -281,12 +281,13 @@ int sf_icp_set_query_order(sf_icp *icp, int order);
  * search is skipped.  Results are bit-identical with the switch on or off (tested); it only
  * changes how much of the "nearest neighbour every iteration" work has to be redone. */
 int sf_icp_set_nn_reuse(sf_icp *icp, int on);
-/* Consecutive sf_icp_align_batch_async calls on unchanged inputs (source, initial poses, target) overlap: the launch list of a
- * batch of two or more scans runs on one of two internal streams in turn, each with its own copy of everything an alignment
- * writes, so an alignment's last launches (with frozen pairs: a chain of 16 us kernels on an idle device) run under the next
- * one's searching launches.  The context's stream waits for every alignment as soon as it is enqueued: a fetch, an upload or
- * a map rebuild issued afterwards is ordered behind it exactly as before, and a changed input makes the next alignment wait
- * for everything before it.  Results are those of the same alignment run alone (same kernels, same data; tested bitwise).
+/* Consecutive sf_icp_align_batch_async calls on unchanged inputs (source, initial poses, target) overlap: a launch list
+ * enqueued while an earlier alignment of this object has not been fetched yet runs on an internal stream with its own copy of
+ * everything an alignment writes, so an alignment's last launches (with frozen pairs: a chain of 16 us kernels on an idle
+ * device) run under the next one's searching launches.  The context's stream waits for every such alignment as soon as it is
+ * enqueued: a fetch, an upload or a map rebuild issued afterwards is ordered behind it exactly as before, and a changed input
+ * makes the next alignment wait for everything before it.  A caller that fetches each result before the next alignment never
+ * leaves the context's stream.  Results are those of the same alignment run alone (same kernels, same data; tested bitwise).
  * on: 1 (default) / 0 = every alignment on the context's stream.  No reference counterpart (one scan at a time,
  * localization_node.cpp:337). */
 int sf_icp_set_pipeline(sf_icp *icp, int on);

@@ -2939,7 +2939,7 @@ struct sf_icp {
     // Consecutive asynchronous alignments of the launch list overlap: an alignment's last launches (frozen pairs: fourteen 16 us
     // kernels on an otherwise idle device) run under the next one's searching launches.  Two LANES take turns; each has its own
     // stream and its own copy of everything an alignment writes (`other` holds the lane that is not in the members of this struct).
-    // Ordering (align_lane_begin / _end): a lane starts after the context's stream as it stood when the inputs -- source, initial poses,
+    // Ordering (LaneScope): a lane starts after the context's stream as it stood when the inputs -- source, initial poses,
     // target -- last changed, and the context's stream waits for every alignment right after it is enqueued, so whatever the caller
     // enqueues next (a fetch, an upload, a map rebuild) is ordered behind it as before; only back-to-back alignments of unchanged
     // inputs run side by side.  Same kernels, same data, same results (tests/test_gpu_pipeline.py).
@@ -2954,6 +2954,8 @@ struct sf_icp {
     int pipeline = 1;             // sf_icp_set_pipeline: 0 = every alignment on the context's stream
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     hipEvent_t lane_done[2] = {nullptr, nullptr}, main_mark = nullptr;
+    bool lane_used[2] = {false, false}; // lane_done[l] has been recorded
+    bool unfetched = false;       // an alignment has been enqueued since the last fetch (the next one may run beside it)
     bool mark_valid = false;      // main_mark stands for the inputs as described by the fields below
     uint64_t src_version = 0, mark_src_version = 0, mark_map_generation = 0;
     const void *mark_map = nullptr;
@@ -4106,28 +4108,29 @@ int lane_reserve(sf_icp *icp)
     return SF_OK;
 }
 
-// RAII around the enqueue of one alignment: on a lane (piped) the context's stream is the lane's for the duration
+// RAII around the enqueue of one alignment.  An alignment enqueued while an earlier one of this object has not been fetched yet
+// (back-to-back sf_icp_align_batch_async: the throughput pattern) takes the OTHER lane's buffers and that lane's stream; the
+// first one after a fetch -- and every alignment of a caller that fetches each result before asking for the next -- runs on the
+// context's stream with the buffers it finds, as before.  Per lane an event marks its last alignment, whatever stream it ran on.
 struct LaneScope {
     sf_icp *icp;
     hipStream_t main = nullptr;
     bool piped = false;
     int rc = SF_OK;
-    LaneScope(sf_icp *i, int mode, bool want) : icp(i)
+    LaneScope(sf_icp *i, bool allowed) : icp(i)
     {
-        if (!want) return;
         main = icp->ctx->stream;
+        if (!allowed) return;
         for (int l = 0; l < 2; ++l) {
             if (!icp->lane_stream[l] && hipStreamCreateWithFlags(&icp->lane_stream[l], hipStreamNonBlocking) != hipSuccess) { rc = SF_ERR_HIP; return; }
             if (!icp->lane_done[l] && hipEventCreateWithFlags(&icp->lane_done[l], hipEventDisableTiming) != hipSuccess) { rc = SF_ERR_HIP; return; }
         }
         if (!icp->main_mark && hipEventCreateWithFlags(&icp->main_mark, hipEventDisableTiming) != hipSuccess) { rc = SF_ERR_HIP; return; }
-        lane_flip(icp); // take turns
-        rc = lane_reserve(icp);
-        if (rc != SF_OK) return;
+        // the mark: where the context's stream stood when the inputs last changed (taken before anything of this alignment is enqueued)
         const sf_map *m = icp->map;
         const bool same = icp->mark_valid && icp->mark_src_version == icp->src_version && icp->mark_map == (const void *)m && icp->mark_map_generation == m->generation &&
                           std::memcmp(&icp->mark_window, &m->window, sizeof(SfWindow)) == 0 && icp->mark_inits == icp->inits;
-        if (!same) { // the inputs changed since the mark: everything the context's stream holds up to here comes first
+        if (!same) {
             if (hipEventRecord(icp->main_mark, main) != hipSuccess) { rc = SF_ERR_HIP; return; }
             icp->mark_valid = true;
             icp->mark_src_version = icp->src_version;
@@ -4136,18 +4139,26 @@ struct LaneScope {
             icp->mark_window = m->window;
             icp->mark_inits = icp->inits;
         }
-        if (hipStreamWaitEvent(icp->lane_stream[icp->lane], icp->main_mark, 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
-        icp->ctx->stream = icp->lane_stream[icp->lane];
+        if (!icp->unfetched) return; // nothing of this object in flight: the context's stream, the buffers at hand
+        lane_flip(icp); // take turns
+        rc = lane_reserve(icp);
+        if (rc != SF_OK) return;
+        hipStream_t ls = icp->lane_stream[icp->lane];
+        // after the inputs, and after this lane's previous alignment (which may have run on the context's stream)
+        if (hipStreamWaitEvent(ls, icp->main_mark, 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
+        if (icp->lane_used[icp->lane] && hipStreamWaitEvent(ls, icp->lane_done[icp->lane], 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
+        icp->ctx->stream = ls;
         piped = true;
-        (void)mode;
     }
     ~LaneScope()
     {
-        if (!piped) return;
-        hipStream_t ls = icp->ctx->stream;
+        hipStream_t ran = icp->ctx->stream;
         icp->ctx->stream = main;
+        if (!icp->lane_done[icp->lane]) return; // (not allowed: nothing to mark)
+        if (hipEventRecord(icp->lane_done[icp->lane], ran) != hipSuccess) return;
+        icp->lane_used[icp->lane] = true;
         // whatever the caller enqueues next on the context's stream is ordered behind this alignment
-        if (hipEventRecord(icp->lane_done[icp->lane], ls) == hipSuccess) { hipError_t e = hipStreamWaitEvent(main, icp->lane_done[icp->lane], 0); (void)e; }
+        if (piped) { hipError_t e = hipStreamWaitEvent(main, icp->lane_done[icp->lane], 0); (void)e; }
     }
 };
 } // namespace
@@ -4159,9 +4170,10 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     SF_HIP(hipSetDevice(icp->ctx->device));
     icp->last_mode = mode;
     icp->last_fused = fused_eligible(icp, mode);
-    // the launch list of a batch takes a lane (see sf_icp::Lane); the single launch, profiled runs and a count left on the device stay on the context's stream
-    LaneScope lanes(icp, mode, icp->pipeline != 0 && !icp->last_fused && !icp->profiling && !icp->n_on_device && icp->batch > 1);
+    // the launch list takes a lane (see sf_icp::Lane); the single launch, profiled runs and a count left on the device stay on the context's stream
+    LaneScope lanes(icp, icp->pipeline != 0 && !icp->last_fused && !icp->profiling && !icp->n_on_device);
     SF_TRY(lanes.rc);
+    icp->unfetched = true;
     hipStream_t s = icp->ctx->stream;
     SF_TRY(launch_state_init(icp));
     if (icp->last_fused) { // everything resident at once: the whole alignment is one launch (window and count by value)
@@ -4221,6 +4233,7 @@ extern "C" int sf_icp_fetch_results(sf_icp *icp, sf_icp_result *out)
     SF_CHECK(icp && out, SF_ERR_INVALID, "bad arguments");
     SF_CHECK(icp->batch > 0, SF_ERR_STATE, "nothing to fetch");
     SF_TRY(states_to_host(icp));
+    icp->unfetched = false;
     fused_release(icp); // the grid has drained
     if (icp->profiling) prof_collect(icp);
     SF_TRY(check_barrier_flags(icp));
