@@ -84,3 +84,51 @@ def test_a_target_rebuilt_between_calls(api, ctx, synth, world):
     got = icp.fetch_results()
     alone = make(api, ctx, w, False, True)
     bitwise(got, alone.align_batch("p2plane"))
+
+
+def test_random_call_sequences_equal_the_same_calls_on_one_lane(api, ctx, synth, small_world):
+    """Seeded fuzz: the same random sequence of calls -- asynchronous alignments in all three modes, new priors, new sources, another
+    iteration count, fetches -- on an object with the lanes and on one without; every fetched result must be bit-identical.
+    Small scans through the launch list (sf_icp_set_fused(0)) keep it quick; SF_FUZZ_TRIALS / SF_FUZZ_SEED override the defaults."""
+    import os
+    m = small_world["map"]
+    mp = api.Map(ctx, api.Cloud(ctx, m), 0.25)
+    mp.estimate_normals(0.25)
+    rng = np.random.default_rng(int(os.environ.get("SF_FUZZ_SEED", "5")))
+    pool = [np.stack([synth.make_scan(m, 6000, scan_id=300 + 3 * k + b)[0][:6000] for b in range(3)]) for k in range(3)]
+    objs = []
+    for pipe in (True, False):
+        icp = api.Icp(ctx, 0.5, 8, 0.05, 1e-5)
+        icp.set_target(mp)
+        icp.set_fused(False)
+        icp.use_graph(True)
+        icp.set_pipeline(pipe)
+        icp.set_source_batch(pool[0])
+        icp.set_initial_batch(None)
+        objs.append(icp)
+    pending = False
+    for t in range(int(os.environ.get("SF_FUZZ_TRIALS", "60"))):
+        op = rng.choice(["align", "align", "align", "inits", "source", "iters", "fetch"])
+        if op == "align":
+            mode = str(rng.choice(["p2plane", "o3d_p2p", "ref_cpp"]))
+            for icp in objs:
+                icp.align_batch_async(mode)
+            pending = True
+        elif op == "inits":
+            inits = np.stack([synth.make_T(rng.normal(0, 0.02, 3), rng.normal(0, 0.2, 3)) for _ in range(3)])
+            for icp in objs:
+                icp.set_initial_batch(inits)
+        elif op == "source":
+            k = int(rng.integers(0, 3))
+            for icp in objs:
+                icp.set_source_batch(pool[k])
+                icp.set_initial_batch(None)
+            pending = False
+        elif op == "iters":
+            it = int(rng.integers(1, 12))
+            for icp in objs:
+                icp.set_num_iterations(it)
+        elif pending:
+            bitwise(objs[0].fetch_results(), objs[1].fetch_results())
+    if pending:
+        bitwise(objs[0].fetch_results(), objs[1].fetch_results())
