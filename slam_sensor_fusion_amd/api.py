@@ -544,6 +544,11 @@ class Icp:
         code = {False: 0, "off": 0, "auto": 1, True: 2, "always": 2}[on]
         _check(self.lib.sf_icp_set_freeze(self.h, C.c_int(code)))
 
+    def set_wide_scan_points(self, points):
+        """Scans above this many points take the launch list with two queries per lane and may freeze (sf_icp_set_wide_scan_points;
+        default 131 072).  Call before set_source*."""
+        _check(self.lib.sf_icp_set_wide_scan_points(self.h, C.c_int64(int(points))))
+
     def set_pipeline(self, on=True):
         """Overlap of consecutive align_batch_async calls on unchanged inputs (sf_icp_set_pipeline, default on)."""
         _check(self.lib.sf_icp_set_pipeline(self.h, C.c_int(int(bool(on)))))

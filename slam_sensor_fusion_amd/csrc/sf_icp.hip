@@ -2891,7 +2891,8 @@ struct sf_icp {
     int64_t xchg_bytes = 0;
     int nblocks = 0;         // workgroups of 256 points covering a scan (REF_CPP kernels, owned-query compaction)
     int nblocks_nn = 0;      // k_nn_red workgroups per scan = slab rows (256 * qpl queries each)
-    int qpl = 1;             // queries per lane of k_nn_red: 1 up to WIDE_SCAN_POINTS points per scan, SF_WIDE_QPL beyond (part of the summation order)
+    int qpl = 1;             // queries per lane of k_nn_red: 1 up to wide_from points per scan, SF_WIDE_QPL beyond (part of the summation order)
+    int64_t wide_from = WIDE_SCAN_POINTS; // sf_icp_set_wide_scan_points: scans above this many points take two queries per lane (and may freeze)
     std::vector<IcpState> h_state;
     // sharding
     bool shard = false;
@@ -3186,7 +3187,7 @@ int icp_alloc(sf_icp *icp, int64_t n, int batch)
     // device memory), so the launch geometry -- and with it a captured graph -- is shared by scans of similar size
     icp->n_cap = batch == 1 ? sf::div_up(std::max<int64_t>(n, 1), 4096) * 4096 : n;
     icp->nblocks = (int)std::max<int64_t>(1, sf::div_up(icp->n_cap, BLK));
-    icp->qpl = n > WIDE_SCAN_POINTS ? SF_WIDE_QPL : 1;
+    icp->qpl = n > icp->wide_from ? SF_WIDE_QPL : 1;
     icp->nblocks_nn = (int)std::max<int64_t>(1, sf::div_up(n, BLK * icp->qpl));
     SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)REC_STRIDE * (size_t)icp->nblocks * (size_t)batch));
     SF_TRY(icp->xchg_own.reserve(sizeof(double) * REC_STRIDE * (size_t)batch));
@@ -3909,6 +3910,13 @@ extern "C" int sf_icp_set_nn_reuse(sf_icp *icp, int on)
     SF_CHECK(icp, SF_ERR_INVALID, "icp is NULL");
     icp->reuse = on != 0;
     if (icp->graph_exec) { hipError_t e = hipGraphExecDestroy(icp->graph_exec); (void)e; icp->graph_exec = nullptr; } // the captured launches carry the cache pointers
+    return SF_OK;
+}
+
+extern "C" int sf_icp_set_wide_scan_points(sf_icp *icp, int64_t points)
+{
+    SF_CHECK(icp && points >= 1024 && points <= WIDE_SCAN_POINTS, SF_ERR_INVALID, "the limit must lie in [1 024, 131 072] (what the single-launch kernels can take)");
+    icp->wide_from = points; // takes effect with the next source
     return SF_OK;
 }
 

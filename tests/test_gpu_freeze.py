@@ -197,6 +197,34 @@ def test_the_schedule_learnt_from_the_last_alignment_changes_no_result(api, ctx,
     icp.close()
 
 
+def test_a_lower_wide_scan_limit_lets_smaller_scans_freeze(api, ctx, synth, world):
+    """A full 64-ring scan has at most 130 048 returns: below the 131 072-point limit of the single-launch kernels it keeps one
+    query per lane and never freezes.  sf_icp_set_wide_scan_points moves the limit for callers that register such scans in
+    batches: the same pairs, poses equal to float64 rounding, and the scans freeze."""
+    scans = world["scans"][:, :100_000].copy()
+
+    def go(limit, freeze):
+        icp = api.Icp(ctx, 0.5, 20, 0.05, 1e-5)
+        icp.set_target(world["mp"])
+        icp.set_query_order("cell")
+        icp.set_freeze(freeze)
+        if limit:
+            icp.set_wide_scan_points(limit)
+        icp.set_source_batch(scans)
+        icp.set_initial_batch(world["inits"])
+        r = icp.align_batch("p2plane")
+        s = icp.freeze_stats()
+        icp.close()
+        return r, s
+    plain, s0 = go(None, True)
+    assert s0["froze"] == 0                                   # 100 000 points: one query per lane, nothing to freeze
+    wide, s1 = go(65536, True)
+    assert s1["froze"] >= 3 and s1["frozen_at_end"] == 3
+    same_result(wide, plain, tol=1e-10)
+    with pytest.raises(api.SlamFusionError):
+        api.Icp(ctx, 0.5, 20, 0.05, 1e-5).set_wide_scan_points(200_000)
+
+
 def test_a_map_a_kilometre_from_the_origin(api, ctx, orc, synth, world):
     """The moments are taken in un-centred map coordinates: sum r^2 and J^T r are differences of O(N |y|^2) terms, so digits
     go like |y|^2.  Measured with the map 1 km out (1.1 km from the origin): poses still agree with the launch-by-launch

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rings", type=int, nargs="+", default=[64, 128])
     ap.add_argument("--prior", nargs="+", default=["0.06:0.3", "0.3:1.5"], help="1-sigma prior error per axis, metres:degrees")
+    ap.add_argument("--wide-from", type=int, default=131072, help="sf_icp_set_wide_scan_points: 65536 lets a 64-ring scan (127 k points) freeze")
     args = ap.parse_args()
     mode = "p2plane"
     ctx = api.Context(0)
@@ -74,6 +75,7 @@ def main():
             icp = api.Icp(ctx, 0.5, args.iters, 0.05, 1e-5)
             icp.set_target(mp)
             icp.use_graph(True)
+            icp.set_wide_scan_points(args.wide_from)
             icp.set_source_batch(scans)
             icp.set_initial_batch(inits)
             out = {}
@@ -84,7 +86,7 @@ def main():
             out["scans_per_s"] = timed(icp, ctx, mode, args.steps, args.batch)
             fs = icp.freeze_stats()
             out["freeze_stats"] = dict(fs, active_share=fs["active_queries"] / float(n * args.batch), scans=args.batch,
-                                       applicable=bool(n > 131072), note="" if n > 131072 else "scans of at most 131 072 points never freeze (one query per lane, the single-launch summation order)")
+                                       applicable=bool(n > args.wide_from), wide_from=args.wide_from, note="" if n > args.wide_from else "scans of at most 131 072 points never freeze (one query per lane, the single-launch summation order)")
             icp.use_graph(False)
             icp.profile_enable(True)
             icp.align_batch_async(mode)
