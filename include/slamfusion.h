@@ -158,6 +158,19 @@ void sf_map_destroy(sf_map *m);
 int sf_map_build(sf_map *m, sf_cloud *cloud, float cell);
 int sf_map_size(sf_map *m, int64_t *n);
 int sf_map_cell_size(sf_map *m, float *cell, int32_t dims[3]);
+/* The index carried over a growth step (`*map_cloud += *cloud` + voxel filter + setTargetPointCloud:
+ * global_map_frames_manager.cpp:131,142-146, icp_point_to_point.cpp:49-55): exactly sf_map_build(m, cloud, <the cell m has>)
+ * -- points in cell order with their ids, and the cell table, bit for bit -- computed as a MERGE of the old index with the centroids the last
+ * sf_cloud_voxel_merge(cloud, ...) wrote, when `m` indexes `cloud` as it was before that merge and nothing has touched
+ * the cloud since: the entries that stay keep their order (one streaming pass), only the new centroids are sorted.
+ * Takes the build itself whenever that does not hold (the merge took its full path, the cloud changed in between, the
+ * smallest coordinate of the map moved, 64-bit cell ids); *patched (may be NULL) says which way it went.  Normals and
+ * the window are dropped as sf_map_build drops them; re-attach the map to its sf_icp (sf_icp_set_target). */
+int sf_map_patch(sf_map *m, sf_cloud *cloud, int *patched);
+/* the index as it lies in HBM, for parity tests: points indexed, cells, grid origin, 1 / cell, the pruning slack;
+ * pts4 = float[n][4] (x, y, z, bitcast point id) in cell order, cell_start = uint32[n_cells + 1] (either may be NULL) */
+int sf_map_index_info(sf_map *m, int64_t *n_indexed, int64_t *n_cells, float org[3], float *inv_h, float *gap_eps);
+int sf_map_download_index(sf_map *m, float *pts4, int64_t cap_points, uint32_t *cell_start, int64_t cap_cells);
 /* window = the reference's map crop, applied as a predicate inside the search:
  * sphere: d2(center,p) < (float)(radius*radius) like cropPointCloudThroughRadius
  * (localization_node.cpp:302); obb: like localization_node.py:222-225; none: whole map */

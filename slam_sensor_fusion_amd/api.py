@@ -356,6 +356,22 @@ class Map:
         _check(self.lib.sf_map_build(self.h, cloud.h, C.c_float(cell)))
         return self
 
+    def patch(self, cloud):
+        """sf_map_patch: the index after the last `cloud.voxel_merge(...)`, merged from the old one when it can be; -> True if it was."""
+        done = C.c_int(0)
+        _check(self.lib.sf_map_patch(self.h, cloud.h, C.byref(done)))
+        return bool(done.value)
+
+    def index(self):
+        """The index as it lies on the device (parity tests): dict(pts4 [n, 4] float32 with the point id bit-cast into column 3,
+        cell_start [cells + 1] uint32, org, inv_h, gap_eps)."""
+        n, nc, org, inv_h, eps = C.c_int64(), C.c_int64(), (C.c_float * 3)(), C.c_float(), C.c_float()
+        _check(self.lib.sf_map_index_info(self.h, C.byref(n), C.byref(nc), org, C.byref(inv_h), C.byref(eps)))
+        pts4 = np.empty((max(n.value, 1), 4), np.float32)
+        cs = np.empty(nc.value + 1, np.uint32)
+        _check(self.lib.sf_map_download_index(self.h, pts4.ctypes.data_as(C.c_void_p), C.c_int64(len(pts4)), cs.ctypes.data_as(C.c_void_p), C.c_int64(len(cs))))
+        return dict(pts4=pts4[:n.value], cell_start=cs, org=np.array(list(org), np.float32), inv_h=inv_h.value, gap_eps=eps.value)
+
     def __len__(self):
         n = C.c_int64()
         _check(self.lib.sf_map_size(self.h, C.byref(n)))

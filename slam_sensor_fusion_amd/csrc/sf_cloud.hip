@@ -176,6 +176,7 @@ static void cloud_reset_meta(sf_cloud *c)
 extern "C" int sf_cloud_upload(sf_cloud *c, const float *xyz, int64_t n)
 {
     SF_CHECK(c && n >= 0 && (xyz || n == 0), SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(c);
     SF_HIP(hipSetDevice(c->ctx->device));
     SF_TRY(c->xyz.reserve(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1)));
     if (n > 0) SF_TRY(sf::upload_staged(c->ctx, c->xyz.p, xyz, sizeof(float) * 3 * (size_t)n)); // stream-ordered; the caller may free xyz on return
@@ -189,6 +190,7 @@ extern "C" int sf_cloud_upload(sf_cloud *c, const float *xyz, int64_t n)
 extern "C" int sf_cloud_upload_async(sf_cloud *c, const float *xyz, int64_t n)
 {
     SF_CHECK(c && n >= 0 && (xyz || n == 0), SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(c);
     SF_HIP(hipSetDevice(c->ctx->device));
     SF_TRY(c->xyz.reserve(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1)));
     if (n > 0) SF_HIP(hipMemcpyAsync(c->xyz.p, xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, c->ctx->stream));
@@ -197,11 +199,16 @@ extern "C" int sf_cloud_upload_async(sf_cloud *c, const float *xyz, int64_t n)
     return SF_OK;
 }
 
-extern "C" void *sf_cloud_device_ptr(sf_cloud *c) { return c ? c->xyz.p : nullptr; }
+extern "C" void *sf_cloud_device_ptr(sf_cloud *c)
+{
+    if (c) sf::cloud_touch(c); // whoever holds the pointer may write through it
+    return c ? c->xyz.p : nullptr;
+}
 
 extern "C" int sf_cloud_upload_f64(sf_cloud *c, const double *xyz, int64_t n)
 {
     SF_CHECK(c && n >= 0 && (xyz || n == 0), SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(c);
     std::vector<float> tmp((size_t)n * 3);
     for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = (float)xyz[i];
     return sf_cloud_upload(c, tmp.data(), n);
@@ -210,6 +217,7 @@ extern "C" int sf_cloud_upload_f64(sf_cloud *c, const double *xyz, int64_t n)
 extern "C" int sf_cloud_from_device(sf_cloud *c, const void *d_xyz, int64_t n)
 {
     SF_CHECK(c && n >= 0 && (d_xyz || n == 0), SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(c);
     SF_HIP(hipSetDevice(c->ctx->device));
     SF_TRY(c->xyz.reserve(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1)));
     if (n > 0)
@@ -222,6 +230,7 @@ extern "C" int sf_cloud_from_device(sf_cloud *c, const void *d_xyz, int64_t n)
 extern "C" int sf_cloud_copy(sf_cloud *dst, sf_cloud *src)
 {
     SF_CHECK(dst && src, SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(dst);
     return sf_cloud_from_device(dst, src->xyz.p, src->n);
 }
 
@@ -460,6 +469,7 @@ inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)sf::div_up(n > 0
 extern "C" int sf_cloud_subsample(sf_cloud *c, int step)
 {
     SF_CHECK(c && step > 0, SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(c);
     SF_HIP(hipSetDevice(c->ctx->device));
     if (c->n < step) { // point_cloud_processing.hpp:58-61: untouched
         c->n_last_idx = -1;
@@ -480,6 +490,7 @@ extern "C" int sf_cloud_subsample(sf_cloud *c, int step)
 extern "C" int sf_cloud_crop_radius(sf_cloud *c, const float center[3], double radius, int sorted)
 {
     SF_CHECK(c && center, SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(c);
     SF_HIP(hipSetDevice(c->ctx->device));
     sf_ctx *ctx = c->ctx;
     int64_t n = c->n;
@@ -530,6 +541,7 @@ extern "C" int sf_cloud_crop_radius(sf_cloud *c, const float center[3], double r
 extern "C" int sf_cloud_remove_floor(sf_cloud *c)
 {
     SF_CHECK(c, SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(c);
     SF_HIP(hipSetDevice(c->ctx->device));
     if (c->n == 0) { c->n_last_idx = 0; return SF_OK; }
     sf::DevBuf &flags = c->flags;
@@ -541,6 +553,7 @@ extern "C" int sf_cloud_remove_floor(sf_cloud *c)
 extern "C" int sf_cloud_crop_aabb(sf_cloud *c, const double lo[3], const double hi[3])
 {
     SF_CHECK(c && lo && hi, SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(c);
     SF_HIP(hipSetDevice(c->ctx->device));
     if (c->n == 0) { c->n_last_idx = 0; return SF_OK; }
     Box b;
@@ -554,6 +567,7 @@ extern "C" int sf_cloud_crop_aabb(sf_cloud *c, const double lo[3], const double 
 extern "C" int sf_cloud_crop_obb(sf_cloud *c, const double center[3], const double R[9], const double extent[3])
 {
     SF_CHECK(c && center && R && extent, SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(c);
     SF_HIP(hipSetDevice(c->ctx->device));
     if (c->n == 0) { c->n_last_idx = 0; return SF_OK; }
     Obb o;
@@ -568,6 +582,7 @@ extern "C" int sf_cloud_crop_obb(sf_cloud *c, const double center[3], const doub
 extern "C" int sf_cloud_transform(sf_cloud *c, const float T[16])
 {
     SF_CHECK(c && T, SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(c);
     SF_HIP(hipSetDevice(c->ctx->device));
     if (c->n == 0) return SF_OK;
     Aff a;
@@ -582,6 +597,7 @@ extern "C" int sf_cloud_transform(sf_cloud *c, const float T[16])
 extern "C" int sf_cloud_append(sf_cloud *dst, const sf_cloud *src)
 {
     SF_CHECK(dst && src && dst != src, SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(dst);
     SF_CHECK(dst->ctx->device == src->ctx->device, SF_ERR_INVALID, "clouds live on different devices");
     SF_CHECK(dst->n + src->n < (int64_t)0x7fffffff, SF_ERR_OVERFLOW, "cloud too large for 32-bit point ids");
     SF_HIP(hipSetDevice(dst->ctx->device));
@@ -731,6 +747,7 @@ extern "C" int sf_cloud_from_pointcloud2_msg(sf_cloud *c, const void *data, int6
                                              int off_x, int off_y, int off_z, int datatype, int is_bigendian)
 {
     SF_CHECK(c && width >= 0 && height >= 0 && data_bytes >= 0, SF_ERR_INVALID, "bad arguments");
+    sf::cloud_touch(c);
     SF_CHECK(!is_bigendian, SF_ERR_INVALID, "big-endian PointCloud2 payloads are not supported");
     SF_CHECK(datatype == SF_PC2_FLOAT32 || datatype == SF_PC2_FLOAT64, SF_ERR_INVALID, "x/y/z datatype %d: FLOAT32 (7) or FLOAT64 (8) expected", datatype);
     const int fsz = datatype == SF_PC2_FLOAT64 ? 8 : 4;

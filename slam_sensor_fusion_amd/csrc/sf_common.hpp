@@ -100,6 +100,7 @@ struct sf_ctx {
     sf::DevBuf scratch2;  // block counts / small reductions
     sf::DevBuf sort_hist, scan_tiles; // sf_sort.hpp: digit histograms of the radix sort, tile sums of the scans
     sf::DevBuf merge_tmp;  // sf_cloud_voxel_merge: per-voxel tables of the pending points
+    uint64_t merge_epoch = 0; // bumped by every merge that rewrites merge_tmp (sf_cloud::MergeRecord::epoch)
     sf::DevBuf vox_tmp[6]; // voxel grids: keys, keys', point ids, point ids', head flags, positions -- kept between calls (a growing map re-voxelises every few scans)
     void *h_pinned = nullptr; // small pinned staging (4 KiB)
     // pageable -> device uploads go through two pinned buffers in turn (sf::upload_staged): the runtime's own staging of
@@ -125,6 +126,27 @@ struct sf_cloud {
     sf::DevBuf vox_point_ids; int64_t n_vox_point_vals = 0;
     sf::DevBuf vox_out_ids;   int64_t n_vox_out_vals = 0;
     sf::DevBuf vox_out_means; int64_t n_vox_out_pts = 0; // float64 means (O3D flavour)
+    // process-unique stamp of the contents: every call that may change the points takes a new one (sf::cloud_touch).
+    // sf_map_build remembers the stamp it indexed; sf_map_patch (sf_map.hip) only trusts an index whose stamp is the one
+    // the last merge started from.
+    uint64_t stamp = 0;
+    // bounds of the points when all are finite and nothing has changed since (stamp == bounds_stamp): a merge knows the bounds it
+    // leaves behind unless it replaced a point that held one, so the next merge need not reduce over the map again
+    uint64_t bounds_stamp = 0;
+    float bounds_mn[3] = {0, 0, 0}, bounds_mx[3] = {0, 0, 0};
+    // what the last sf_cloud_voxel_merge that took the merge path did, for sf_map_patch: the tables live in ctx->merge_tmp
+    // (valid while ctx->merge_epoch == epoch and stamp == stamp_after)
+    struct MergeRecord {
+        bool valid = false;
+        uint64_t epoch = 0, stamp_before = 0, stamp_after = 0;
+        int64_t n_old = 0, n_groups = 0, n_fresh = 0;
+        float old_mn[3] = {0, 0, 0}, old_mx[3] = {0, 0, 0}; // bounds of the map before the merge
+        float cen_mn[3] = {0, 0, 0}, cen_mx[3] = {0, 0, 0}; // bounds of the centroids it wrote
+        bool touched_extreme = false;                       // an old point holding one of the old bounds was replaced: the new bounds are not known without a pass
+        const uint32_t *coarse = nullptr;                                                                   // [n_old / 64 + 2]: fresh voxels whose rank is below 64 b
+        const uint32_t *g_rank = nullptr, *g_fresh = nullptr, *fresh_pos = nullptr, *fresh_rank = nullptr; // per voxel of the pending points: rank among the old points, 1 = not in the old map, fresh voxels before it; the ranks of the fresh ones
+        const float *g_centroid = nullptr, *g_old = nullptr;                                               // its centroid (old point first, then the pending ones); the old point it replaces
+    } merge;
 };
 
 // window predicate applied inside the NN search (the reference's map crop)
@@ -151,7 +173,11 @@ struct SfGrid {
 
 struct sf_map {
     sf_ctx *ctx = nullptr;
-    sf::DevBuf pts4, nrm4, cell_start, keys, vals, keys2, vals2, inv_perm;
+    sf::DevBuf pts4, nrm4, cell_start, keys, vals, keys2, vals2;
+    sf::DevBuf pts4_alt, patch_tmp; // sf_map_patch writes the patched index beside the old one and swaps
+    double h_exact = 0;       // the cell as sf_map_build chose it
+    float src_mx[3] = {0, 0, 0}; // largest coordinates of the indexed cloud (grid.org holds the smallest)
+    uint64_t src_stamp = 0;   // sf_cloud::stamp of the cloud the index describes
     sf::DevBuf d_window; // the window in device memory (REF_CPP kernels read it there: a captured launch list survives a moving crop)
     sf::DevBuf cov6;   // optional: the 6 unique entries of each point's neighbourhood covariance (sorted order), sf_map_estimate_normals
     int64_t n = 0;
@@ -173,6 +199,7 @@ int ensure_scratch(sf_ctx *ctx, size_t bytes);
 // dst (device) <- src (any host memory), stream-ordered on the context's stream; src may be freed on return
 int upload_staged(sf_ctx *ctx, void *dst, const void *src, size_t bytes);
 uint64_t next_generation();
+inline void cloud_touch(sf_cloud *c) { c->stamp = next_generation(); c->merge.valid = false; }
 // children keep their context alive: any destruction order is safe
 void ctx_retain(sf_ctx *ctx);
 void ctx_release(sf_ctx *ctx);

@@ -12,6 +12,7 @@
 
 #include "sf_sort.hpp"
 #include <cmath>
+#include <cstring>
 
 namespace {
 
@@ -53,13 +54,12 @@ __global__ void k_cell_tails(const K *__restrict__ keys, int64_t n_valid, uint32
 
 __global__ void k_carry_max(uint32_t *__restrict__ p) { p[0] = max(p[0], p[-1]); }
 
-__global__ void k_gather_sorted(const float *__restrict__ xyz, const uint32_t *__restrict__ vals, int64_t n, float4 *__restrict__ pts4, uint32_t *__restrict__ inv_perm)
+__global__ void k_gather_sorted(const float *__restrict__ xyz, const uint32_t *__restrict__ vals, int64_t n, float4 *__restrict__ pts4)
 {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     uint32_t i = vals[j];
     pts4[j] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __uint_as_float(i));
-    inv_perm[i] = (uint32_t)j;
 }
 
 // cell_start[c] = first sorted position whose key >= c, for c in [0, ncell] (tables below 2^28 cells: the gaps are short)
@@ -100,6 +100,39 @@ __global__ __launch_bounds__(256) void k_map_nn_t(SfGrid g, SfWindow w, const fl
 }
 } // namespace
 
+namespace {
+// cell_start[0 .. ncell] (+ pads) from the sorted keys of the n_valid indexed points; the buffer is reserved by the caller
+int build_cell_table(sf_map *m, const GridGeom &g, const void *sorted_keys, int64_t n_valid, bool wide, bool by_scan)
+{
+    sf_ctx *ctx = m->ctx;
+    hipStream_t st = ctx->stream;
+    uint32_t *cs = m->cell_start.as<uint32_t>() + 1;
+    if (by_scan && n_valid > 0) {
+        // [pad = 0 | t[0..ncell] | pads]: ends of the non-empty cells, then an inclusive max scan in pieces of 2^30 entries
+        // (the carry is the entry before the piece); the trailing pads come out as n_valid like the rest of the tail
+        const size_t entries = (size_t)g.ncell + 8;
+        SF_HIP(hipMemsetAsync(m->cell_start.p, 0, sizeof(uint32_t) * entries, st));
+        if (wide) hipLaunchKernelGGL(k_cell_tails<uint64_t>, dim3(nblk(n_valid)), dim3(256), 0, st, static_cast<const uint64_t *>(sorted_keys), n_valid, cs);
+        else hipLaunchKernelGGL(k_cell_tails<uint32_t>, dim3(nblk(n_valid)), dim3(256), 0, st, static_cast<const uint32_t *>(sorted_keys), n_valid, cs);
+        const size_t piece = (size_t)1 << 30;
+        uint32_t *t = m->cell_start.as<uint32_t>();
+        for (size_t off = 0; off < entries; off += piece) {
+            const size_t len = std::min(piece, entries - off);
+            if (off > 0) hipLaunchKernelGGL(k_carry_max, dim3(1), dim3(1), 0, st, t + off);
+            SF_TRY(sf::scan_u32<1>(ctx, t + off, t + off, (int64_t)len)); // (the carry of a later piece sits in its first entry: k_carry_max)
+        }
+    } else {
+        hipLaunchKernelGGL(k_fill_u32, dim3(nblk((int64_t)g.ncell + 8)), dim3(256), 0, st, m->cell_start.as<uint32_t>(), (int64_t)g.ncell + 8, (uint32_t)n_valid);
+        SF_HIP(hipMemsetAsync(m->cell_start.p, 0, sizeof(uint32_t), st));
+        if (n_valid > 0)
+            hipLaunchKernelGGL(k_cell_bounds, dim3(nblk(n_valid)), dim3(256), 0, st, static_cast<const uint32_t *>(sorted_keys), n_valid, (uint32_t)g.ncell, cs);
+        else
+            hipLaunchKernelGGL(k_fill_u32, dim3(nblk((int64_t)g.ncell + 2)), dim3(256), 0, st, cs, (int64_t)g.ncell + 2, 0u);
+    }
+    return SF_OK;
+}
+} // namespace
+
 extern "C" int sf_map_create(sf_ctx *ctx, sf_map **out)
 {
     SF_CHECK(ctx && out, SF_ERR_INVALID, "bad arguments");
@@ -117,7 +150,7 @@ extern "C" void sf_map_destroy(sf_map *m)
     hipError_t e = hipStreamSynchronize(m->ctx->stream);
     (void)e;
     m->pts4.release(); m->nrm4.release(); m->cov6.release(); m->d_window.release(); m->cell_start.release(); m->keys.release(); m->vals.release();
-    m->keys2.release(); m->vals2.release(); m->inv_perm.release();
+    m->keys2.release(); m->vals2.release(); m->pts4_alt.release(); m->patch_tmp.release();
     sf_ctx *ctx = m->ctx;
     delete m;
     sf::ctx_release(ctx);
@@ -160,6 +193,7 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
     const double max_cells = std::min(34359738368.0, std::max(1.0e9, (double)free_b / 4.0 / sizeof(uint32_t)));
     int dim[3];
     for (;;) {
+        h = (double)(float)h; // the cell is a float32 everywhere else (sf_map_cell_size, SfGrid::h): a rebuild with the reported cell is the same index
         double cells = 1;
         bool ok = true;
         for (int d = 0; d < 3; ++d) {
@@ -186,7 +220,6 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
     SF_TRY(m->keys2.reserve(ksz * np));
     SF_TRY(m->vals2.reserve(sizeof(uint32_t) * np));
     SF_TRY(m->pts4.reserve(sizeof(float4) * np));
-    SF_TRY(m->inv_perm.reserve(sizeof(uint32_t) * np));
     SF_TRY(m->cell_start.reserve(sizeof(uint32_t) * ((size_t)g.ncell + 8))); // [pad | start[0..ncell] | pad..]: sf_nn.hpp reads start[c-1..c+2] in one load
     const void *sorted_keys = m->keys2.p; // where the sort leaves its result (either ping-pong buffer)
     uint32_t *sorted_vals = m->vals2.as<uint32_t>();
@@ -205,31 +238,9 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
             SF_TRY(sf::radix_sort_pairs<uint32_t>(ctx, m->keys.as<uint32_t>(), m->keys2.as<uint32_t>(), m->vals.as<uint32_t>(), m->vals2.as<uint32_t>(), n, bits, &sk, &sorted_vals));
             sorted_keys = sk;
         }
-        hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n)), dim3(256), 0, st, xyz, sorted_vals, n, m->pts4.as<float4>(), m->inv_perm.as<uint32_t>());
+        hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n)), dim3(256), 0, st, xyz, sorted_vals, n, m->pts4.as<float4>());
     }
-    uint32_t *cs = m->cell_start.as<uint32_t>() + 1;
-    if (by_scan && n_valid > 0) {
-        // [pad = 0 | t[0..ncell] | pads]: ends of the non-empty cells, then an inclusive max scan in pieces of 2^30 entries
-        // (the carry is the entry before the piece); the trailing pads come out as n_valid like the rest of the tail
-        const size_t entries = (size_t)g.ncell + 8;
-        SF_HIP(hipMemsetAsync(m->cell_start.p, 0, sizeof(uint32_t) * entries, st));
-        if (wide) hipLaunchKernelGGL(k_cell_tails<uint64_t>, dim3(nblk(n_valid)), dim3(256), 0, st, static_cast<const uint64_t *>(sorted_keys), n_valid, cs);
-        else hipLaunchKernelGGL(k_cell_tails<uint32_t>, dim3(nblk(n_valid)), dim3(256), 0, st, static_cast<const uint32_t *>(sorted_keys), n_valid, cs);
-        const size_t piece = (size_t)1 << 30;
-        uint32_t *t = m->cell_start.as<uint32_t>();
-        for (size_t off = 0; off < entries; off += piece) {
-            const size_t len = std::min(piece, entries - off);
-            if (off > 0) hipLaunchKernelGGL(k_carry_max, dim3(1), dim3(1), 0, st, t + off);
-            SF_TRY(sf::scan_u32<1>(ctx, t + off, t + off, (int64_t)len)); // (the carry of a later piece sits in its first entry: k_carry_max)
-        }
-    } else {
-        hipLaunchKernelGGL(k_fill_u32, dim3(nblk((int64_t)g.ncell + 8)), dim3(256), 0, st, m->cell_start.as<uint32_t>(), (int64_t)g.ncell + 8, (uint32_t)n_valid);
-        SF_HIP(hipMemsetAsync(m->cell_start.p, 0, sizeof(uint32_t), st));
-        if (n_valid > 0)
-            hipLaunchKernelGGL(k_cell_bounds, dim3(nblk(n_valid)), dim3(256), 0, st, static_cast<const uint32_t *>(sorted_keys), n_valid, (uint32_t)g.ncell, cs);
-        else
-            hipLaunchKernelGGL(k_fill_u32, dim3(nblk((int64_t)g.ncell + 2)), dim3(256), 0, st, cs, (int64_t)g.ncell + 2, 0u);
-    }
+    SF_TRY(build_cell_table(m, g, sorted_keys, n_valid, wide, by_scan));
     SF_HIP(hipGetLastError());
     SF_HIP(hipStreamSynchronize(st));
 
@@ -249,6 +260,297 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
     m->built = true;
     m->has_cov = false;
     m->generation = sf::next_generation();
+    m->h_exact = h;
+    for (int d = 0; d < 3; ++d) m->src_mx[d] = n_valid > 0 ? mm.mx[d] : 0.0f;
+    m->src_stamp = cloud->stamp;
+    return SF_OK;
+}
+
+// ------------------------------------------------------------------ the index carried over a map growth step
+// `*map_cloud += *cloud` + voxel filter + setTargetPointCloud (global_map_frames_manager.cpp:131,142-146,
+// icp_point_to_point.cpp:49-55) when the filter ran as a merge (sf_cloud_voxel_merge): the merge knows which old points
+// stay (their ids move up by the fresh voxels in front of them), which are replaced by a new centroid and which voxels are
+// new.  With the grid origin unchanged, a point's cell coordinates are what they were, the cell-sorted order of the points that
+// stay is what it was (ascending id inside a cell, and ids keep their order), and the new index is a MERGE of two sorted
+// sequences: the old entries minus the replaced ones, and the centroids sorted by (cell, id).  One streaming pass over the
+// old entries instead of four sort passes and a random gather; the result is bit-identical to sf_map_build of the merged
+// cloud with the same cell (tests/test_gpu_map_growth.py).  Anything this cannot express -- the smallest coordinate of
+// the map changed, a point that sat clamped at the old upper face, 64-bit cell ids -- takes the build.
+namespace {
+
+struct PatchGeom { float org[3]; float inv_h; int dim[3]; int old_dim[3]; };
+
+__device__ __forceinline__ uint32_t patch_key(const PatchGeom &g, float x, float y, float z, bool *moved)
+{
+    const int cx = (int)fminf(fmaxf(floorf((x - g.org[0]) * g.inv_h), 0.0f), (float)(g.dim[0] - 1));
+    const int cy = (int)fminf(fmaxf(floorf((y - g.org[1]) * g.inv_h), 0.0f), (float)(g.dim[1] - 1));
+    const int cz = (int)fminf(fmaxf(floorf((z - g.org[2]) * g.inv_h), 0.0f), (float)(g.dim[2] - 1));
+    if (moved) *moved = cx > g.old_dim[0] - 1 || cy > g.old_dim[1] - 1 || cz > g.old_dim[2] - 1; // the old grid clamped it into another cell
+    return ((uint32_t)cz * (uint32_t)g.dim[1] + (uint32_t)cy) * (uint32_t)g.dim[0] + (uint32_t)cx;
+}
+
+struct PatchFlags { uint32_t moved, pad; };
+
+// thread t in two roles.  As voxel g = t: key of its centroid, and the old entry it replaces marked in the bitmap over the old
+// sorted positions (+ the count of its block of 256 positions)
+__global__ void k_patch_groups(PatchGeom geo, const uint32_t *__restrict__ g_rank, const uint32_t *__restrict__ g_fresh, const float *__restrict__ g_centroid,
+                               const float *__restrict__ g_old, int64_t n_groups, const float4 *__restrict__ pts, int64_t n_old, uint32_t *__restrict__ ins_key,
+                               uint32_t *__restrict__ ins_val, uint32_t *__restrict__ bitmap, uint32_t *__restrict__ blk_cnt, PatchFlags *__restrict__ ext)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    ins_key[g] = patch_key(geo, g_centroid[3 * g], g_centroid[3 * g + 1], g_centroid[3 * g + 2], nullptr);
+    ins_val[g] = (uint32_t)g;
+    if (!g_fresh[g]) { // the old point of this voxel: where it lies in the index (entries ascend in (cell, id))
+        const uint32_t r = g_rank[g], key = patch_key(geo, g_old[3 * g], g_old[3 * g + 1], g_old[3 * g + 2], nullptr);
+        int64_t lo = 0, hi = n_old;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            const float4 a = pts[mid];
+            const uint32_t k = patch_key(geo, a.x, a.y, a.z, nullptr);
+            if (k < key || (k == key && __float_as_uint(a.w) < r)) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo >= n_old || __float_as_uint(pts[lo].w) != r) { ext->moved = 1u; return; } // (an order the search cannot follow: the build decides)
+        const uint32_t p = (uint32_t)lo;
+        atomicOr(&bitmap[p >> 5], 1u << (p & 31u));
+        atomicAdd(&blk_cnt[p >> 8], 1u);
+    }
+}
+
+// sorted centroid e -> (cell, rank among the old ids) in one word: old entry (cell', id) comes after it iff packed(e) <= (cell' << 32 | id)
+__global__ void k_patch_pack(const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval, const uint32_t *__restrict__ g_rank, int64_t n_groups, uint64_t *__restrict__ packed)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_groups) packed[e] = ((uint64_t)skey[e] << 32) | (uint64_t)g_rank[sval[e]];
+}
+
+// per block of 256 old entries: its candidates among the sorted centroids, [first with cell >= the block's first cell, first with
+// cell > its last cell) -- searched by one thread per bound, all blocks at once (inside k_patch_old the same two searches
+// were a serial chain of ~18 dependent loads in front of every workgroup)
+__global__ void k_patch_ranges(PatchGeom geo, const float4 *__restrict__ pts, int64_t n_old, const uint64_t *__restrict__ packed, int64_t n_groups, int64_t n_blocks,
+                               uint32_t *__restrict__ range)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n_blocks) return;
+    const int64_t blk = t >> 1, p0 = blk * 256;
+    const bool upper = (t & 1) != 0;
+    const float4 a = pts[upper ? min(p0 + 255, n_old - 1) : p0];
+    const uint64_t k = (uint64_t)patch_key(geo, a.x, a.y, a.z, nullptr) << 32;
+    const uint64_t v = upper ? (k | 0xffffffffull) : k;
+    int64_t lo = 0, hi = n_groups;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (upper ? packed[mid] <= v : packed[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    range[t] = (uint32_t)lo;
+}
+
+__device__ __forceinline__ uint32_t patch_del_before(const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ blk_pre, uint32_t p)
+{
+    const uint32_t blk = p >> 8, w = (p & 255u) >> 5;
+    uint32_t c = blk_pre[blk];
+    for (uint32_t k = 0; k < w; ++k) c += (uint32_t)__popc(bitmap[blk * 8u + k]);
+    return c + (uint32_t)__popc(bitmap[blk * 8u + w] & ((1u << (p & 31u)) - 1u));
+}
+
+// one lane per OLD entry, in sorted order: where it goes, with its new id
+__global__ __launch_bounds__(256) void k_patch_old(PatchGeom geo, const float4 *__restrict__ pts, int64_t n_old, const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ blk_pre,
+                                                    const uint64_t *__restrict__ packed, const uint32_t *__restrict__ range, const uint32_t *__restrict__ coarse,
+                                                    const uint32_t *__restrict__ fresh_rank,
+                                                    float4 *__restrict__ pts_out, uint32_t *__restrict__ keys_out, PatchFlags *__restrict__ ext)
+{
+    __shared__ uint32_t words[8], wpre[8];
+    const int64_t p0 = (int64_t)blockIdx.x * 256, p = p0 + threadIdx.x;
+    if (threadIdx.x >= 64 && threadIdx.x < 72) words[threadIdx.x - 64] = bitmap[(size_t)blockIdx.x * 8 + (threadIdx.x - 64)];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = blk_pre[blockIdx.x];
+        for (int k = 0; k < 8; ++k) { wpre[k] = c; c += (uint32_t)__popc(words[k]); }
+    }
+    __syncthreads();
+    if (p >= n_old) return;
+    const uint32_t w = threadIdx.x >> 5, bit = threadIdx.x & 31u;
+    if ((words[w] >> bit) & 1u) return; // replaced by a centroid
+    const float4 a = pts[p];
+    bool moved;
+    const uint32_t key = patch_key(geo, a.x, a.y, a.z, &moved);
+    if (moved) ext->moved = 1u;
+    const uint32_t j = __float_as_uint(a.w);
+    const uint64_t mine = ((uint64_t)key << 32) | (uint64_t)j;
+    int64_t lo = range[2 * (size_t)blockIdx.x], hi = range[2 * (size_t)blockIdx.x + 1]; // centroids that sort before this entry: packed <= mine
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (packed[mid] <= mine) lo = mid + 1;
+        else hi = mid;
+    }
+    uint32_t f = coarse[j >> 6];
+    const uint32_t f_end = coarse[(j >> 6) + 1];
+    while (f < f_end && fresh_rank[f] <= j) ++f;
+    const uint32_t del = wpre[w] + (uint32_t)__popc(words[w] & ((1u << bit) - 1u));
+    const size_t o = (size_t)p - (size_t)del + (size_t)lo;
+    const uint32_t id = j + f;
+    pts_out[o] = make_float4(a.x, a.y, a.z, __uint_as_float(id));
+    keys_out[o] = key;
+}
+
+// one lane per centroid, in (cell, id) order: the old entries in front of it, less the replaced ones, plus its own rank
+__global__ __launch_bounds__(256) void k_patch_new(PatchGeom geo, const float4 *__restrict__ pts, int64_t n_old, const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ blk_pre,
+                                                    const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval, int64_t n_groups, const uint32_t *__restrict__ g_rank,
+                                                    const uint32_t *__restrict__ fresh_pos, const float *__restrict__ g_centroid, float4 *__restrict__ pts_out,
+                                                    uint32_t *__restrict__ keys_out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_groups) return;
+    const uint32_t key = skey[e], g = sval[e], r = g_rank[g];
+    int64_t lo = 0, hi = n_old; // old entries with (cell, id) < (key, r)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const float4 a = pts[mid];
+        const uint32_t k = patch_key(geo, a.x, a.y, a.z, nullptr);
+        if (k < key || (k == key && __float_as_uint(a.w) < r)) lo = mid + 1;
+        else hi = mid;
+    }
+    const size_t o = (size_t)e + (size_t)lo - (size_t)patch_del_before(bitmap, blk_pre, (uint32_t)lo);
+    const uint32_t id = r + fresh_pos[g];
+    pts_out[o] = make_float4(g_centroid[3 * (size_t)g], g_centroid[3 * (size_t)g + 1], g_centroid[3 * (size_t)g + 2], __uint_as_float(id));
+    keys_out[o] = key;
+}
+
+} // namespace
+
+extern "C" int sf_map_patch(sf_map *m, sf_cloud *cloud, int *patched)
+{
+    SF_CHECK(m && cloud, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(m->built, SF_ERR_STATE, "sf_map_patch: the map has no index yet (sf_map_build)");
+    SF_CHECK(m->ctx == cloud->ctx, SF_ERR_INVALID, "map and cloud must live on the same context");
+    if (patched) *patched = 0;
+    sf_ctx *ctx = m->ctx;
+    SF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const float cell = (float)m->h_exact;
+    const sf_cloud::MergeRecord &rec = cloud->merge;
+    const SfGrid old = m->grid;
+    const uint64_t old_cells = (uint64_t)old.dim[0] * (uint64_t)old.dim[1] * (uint64_t)old.dim[2];
+    const int64_t n_old = rec.n_old, ng = rec.n_groups, n_out = cloud->n;
+    if (!rec.valid || rec.epoch != ctx->merge_epoch || rec.stamp_after != cloud->stamp || rec.stamp_before != m->src_stamp || n_old != m->n || old.n != m->n || ng <= 0 ||
+        n_out != n_old + rec.n_fresh || n_out >= (int64_t)(1 << 28) || old_cells >= 0xffffffffull)
+        return sf_map_build(m, cloud, cell);
+
+    // 1. do the bounds of the map survive?  (the merge looked: sf_voxel.hip, k_merge_extremes)
+    if (rec.touched_extreme) return sf_map_build(m, cloud, cell);
+    float new_mx[3];
+    for (int d = 0; d < 3; ++d) {
+        if (rec.old_mn[d] != old.org[d] || rec.old_mx[d] != m->src_mx[d]) return sf_map_build(m, cloud, cell); // (not the bounds this index was built on)
+        if (!(rec.cen_mn[d] > old.org[d])) return sf_map_build(m, cloud, cell); // the origin would move: every cell changes
+        new_mx[d] = std::max(m->src_mx[d], rec.cen_mx[d]);
+    }
+
+    // 2. the geometry a build of the merged cloud would choose (sf_map_build, step 2, explicit cell)
+    const double h = m->h_exact;
+    size_t free_b = 0, total_b = 0;
+    SF_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += m->cell_start.cap; // (the table being replaced counts as free: the build would reuse it)
+    const double max_cells = std::min(34359738368.0, std::max(1.0e9, (double)free_b / 4.0 / sizeof(uint32_t)));
+    GridGeom g;
+    PatchGeom pg;
+    double cells = 1;
+    for (int d = 0; d < 3; ++d) {
+        const double c = std::floor(((double)new_mx[d] - (double)old.org[d]) / h) + 1;
+        if (c > 2.0e9) return sf_map_build(m, cloud, cell);
+        g.org[d] = pg.org[d] = old.org[d];
+        g.dim[d] = pg.dim[d] = (int)c;
+        pg.old_dim[d] = old.dim[d];
+        cells *= c;
+    }
+    if (cells > max_cells || cells >= 4294967295.0) return sf_map_build(m, cloud, cell);
+    g.inv_h = pg.inv_h = old.inv_h;
+    g.ncell = (uint64_t)g.dim[0] * (uint64_t)g.dim[1] * (uint64_t)g.dim[2];
+    const bool by_scan = g.ncell > (1ull << 28);
+
+    // 3. the centroids in (cell, id) order; the replaced entries as a bitmap over the old sorted positions
+    const int64_t nb256 = sf::div_up(n_old, 256) + 1;
+    const size_t off_key = 0, off_key2 = off_key + 4 * (size_t)ng, off_val = off_key2 + 4 * (size_t)ng, off_val2 = off_val + 4 * (size_t)ng, off_packed = (off_val2 + 4 * (size_t)ng + 7) & ~(size_t)7,
+                 off_bitmap = off_packed + 8 * (size_t)ng, off_cnt = off_bitmap + 4 * 8 * (size_t)nb256, off_pre = off_cnt + 4 * (size_t)nb256, off_range = off_pre + 4 * (size_t)nb256,
+                 off_ext = (off_range + 8 * (size_t)nb256 + 15) & ~(size_t)15, total = off_ext + sizeof(PatchFlags);
+    SF_TRY(m->patch_tmp.reserve(total));
+    unsigned char *base = m->patch_tmp.as<unsigned char>();
+    uint32_t *ins_key = reinterpret_cast<uint32_t *>(base + off_key), *ins_key2 = reinterpret_cast<uint32_t *>(base + off_key2), *ins_val = reinterpret_cast<uint32_t *>(base + off_val),
+             *ins_val2 = reinterpret_cast<uint32_t *>(base + off_val2), *bitmap = reinterpret_cast<uint32_t *>(base + off_bitmap), *blk_cnt = reinterpret_cast<uint32_t *>(base + off_cnt),
+             *blk_pre = reinterpret_cast<uint32_t *>(base + off_pre), *range = reinterpret_cast<uint32_t *>(base + off_range);
+    uint64_t *packed = reinterpret_cast<uint64_t *>(base + off_packed);
+    PatchFlags *d_ext = reinterpret_cast<PatchFlags *>(base + off_ext);
+    PatchFlags *h_ext = reinterpret_cast<PatchFlags *>(static_cast<unsigned char *>(ctx->h_pinned) + 256);
+    SF_TRY(m->pts4_alt.reserve(sizeof(float4) * (size_t)n_out));
+    SF_TRY(m->keys.reserve(sizeof(uint32_t) * (size_t)n_out));
+    SF_HIP(hipMemsetAsync(bitmap, 0, off_range - off_bitmap, st)); // bitmap, block counts, their prefix
+    SF_HIP(hipMemsetAsync(d_ext, 0, sizeof(PatchFlags), st));
+    hipLaunchKernelGGL(k_patch_groups, dim3(nblk(ng)), dim3(256), 0, st, pg, rec.g_rank, rec.g_fresh, rec.g_centroid, rec.g_old, ng, old.pts, n_old, ins_key, ins_val, bitmap, blk_cnt,
+                       d_ext);
+    unsigned bits = 1;
+    while (bits < 32 && (1ull << bits) <= (unsigned long long)g.ncell) ++bits;
+    uint32_t *skey = nullptr, *sval = nullptr;
+    SF_TRY(sf::radix_sort_pairs<uint32_t>(ctx, ins_key, ins_key2, ins_val, ins_val2, ng, bits, &skey, &sval)); // stable: equal cells stay in ascending id
+    hipLaunchKernelGGL(k_patch_pack, dim3(nblk(ng)), dim3(256), 0, st, skey, sval, rec.g_rank, ng, packed);
+    SF_TRY(sf::scan_u32<0>(ctx, blk_cnt, blk_pre, nb256));
+    hipLaunchKernelGGL(k_patch_ranges, dim3(nblk(2 * (nb256 - 1))), dim3(256), 0, st, pg, old.pts, n_old, packed, ng, nb256 - 1, range);
+
+    // 4. the merge
+    float4 *pts_out = m->pts4_alt.as<float4>();
+    uint32_t *keys_out = m->keys.as<uint32_t>();
+    hipLaunchKernelGGL(k_patch_old, dim3(nblk(n_old)), dim3(256), 0, st, pg, old.pts, n_old, bitmap, blk_pre, packed, range, rec.coarse, rec.fresh_rank, pts_out, keys_out, d_ext);
+    hipLaunchKernelGGL(k_patch_new, dim3(nblk(ng)), dim3(256), 0, st, pg, old.pts, n_old, bitmap, blk_pre, skey, sval, ng, rec.g_rank, rec.fresh_pos, rec.g_centroid, pts_out, keys_out);
+    SF_HIP(hipMemcpyAsync(h_ext, d_ext, sizeof(PatchFlags), hipMemcpyDeviceToHost, st));
+
+    // 5. the cell table from the merged keys
+    SF_TRY(m->cell_start.reserve(sizeof(uint32_t) * ((size_t)g.ncell + 8)));
+    SF_TRY(build_cell_table(m, g, keys_out, n_out, false, by_scan));
+    SF_HIP(hipGetLastError());
+    SF_HIP(hipStreamSynchronize(st));
+    m->pts4.swap(m->pts4_alt);
+    if (h_ext->moved) return sf_map_build(m, cloud, cell); // a point that the old grid had clamped to its upper face: its cell, and the order, changed
+
+    m->n = n_out;
+    m->has_normals = false;
+    m->window.kind = 0;
+    SfGrid &G = m->grid;
+    for (int d = 0; d < 3; ++d) G.dim[d] = g.dim[d];
+    G.gap_eps = 1.5f * 2.384186e-7f * (float)std::max(g.dim[0], std::max(g.dim[1], g.dim[2])) * (float)h;
+    G.cell_start = m->cell_start.as<uint32_t>() + 1;
+    G.pts = m->pts4.as<float4>();
+    G.nrm = nullptr;
+    G.n = n_out;
+    m->has_cov = false;
+    m->generation = sf::next_generation();
+    for (int d = 0; d < 3; ++d) m->src_mx[d] = new_mx[d];
+    m->src_stamp = cloud->stamp;
+    if (patched) *patched = 1;
+    return SF_OK;
+}
+
+// the index as it lies in HBM, for the parity tests: pts4 (x, y, z, bitcast id) in cell order, cell_start[0 .. n_cells]
+extern "C" int sf_map_index_info(sf_map *m, int64_t *n_indexed, int64_t *n_cells, float org[3], float *inv_h, float *gap_eps)
+{
+    SF_CHECK(m && m->built, SF_ERR_STATE, "map not built");
+    if (n_indexed) *n_indexed = m->grid.n;
+    if (n_cells) *n_cells = (int64_t)m->grid.dim[0] * (int64_t)m->grid.dim[1] * (int64_t)m->grid.dim[2];
+    if (org) for (int d = 0; d < 3; ++d) org[d] = m->grid.org[d];
+    if (inv_h) *inv_h = m->grid.inv_h;
+    if (gap_eps) *gap_eps = m->grid.gap_eps;
+    return SF_OK;
+}
+
+extern "C" int sf_map_download_index(sf_map *m, float *pts4, int64_t cap_points, uint32_t *cell_start, int64_t cap_cells)
+{
+    SF_CHECK(m && m->built, SF_ERR_STATE, "map not built");
+    sf_ctx *ctx = m->ctx;
+    SF_HIP(hipSetDevice(ctx->device));
+    const int64_t n = m->grid.n, nc = (int64_t)m->grid.dim[0] * (int64_t)m->grid.dim[1] * (int64_t)m->grid.dim[2] + 1;
+    SF_CHECK((!pts4 || cap_points >= n) && (!cell_start || cap_cells >= nc), SF_ERR_INVALID, "buffer too small");
+    if (pts4 && n > 0) SF_HIP(hipMemcpyAsync(pts4, m->pts4.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (cell_start) SF_HIP(hipMemcpyAsync(cell_start, m->grid.cell_start, sizeof(uint32_t) * (size_t)nc, hipMemcpyDeviceToHost, ctx->stream));
+    SF_HIP(hipStreamSynchronize(ctx->stream));
     return SF_OK;
 }
 

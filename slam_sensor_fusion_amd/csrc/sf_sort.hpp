@@ -22,16 +22,21 @@
 namespace sf {
 
 constexpr int SORT_BLK = 256, SORT_ITEMS = 16, SORT_TILE = SORT_BLK * SORT_ITEMS, SORT_WAVES = SORT_BLK / 64;
+constexpr int SORT_ITEMS_SMALL = 4;
+constexpr int64_t SORT_SMALL_N = 1 << 20;
 
-template <class K>
+// ITEMS = keys per thread: SORT_ITEMS for large inputs, SORT_ITEMS_SMALL below SORT_SMALL_N pairs (four times the workgroups
+// and a quarter of the ranking rounds each: a sort of 200 k pairs is bound by its few, long workgroups otherwise)
+template <class K, int ITEMS>
 __global__ __launch_bounds__(SORT_BLK) void k_sort_hist(const K *__restrict__ keys, int64_t n, int shift, uint32_t mask, uint32_t *__restrict__ hist, int ntiles)
 {
+    constexpr int TILE = SORT_BLK * ITEMS;
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0u;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    const int64_t base = (int64_t)blockIdx.x * TILE;
 #pragma unroll
-    for (int it = 0; it < SORT_ITEMS; ++it) {
+    for (int it = 0; it < ITEMS; ++it) {
         const int64_t i = base + it * SORT_BLK + (int)threadIdx.x;
         if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
     }
@@ -82,26 +87,27 @@ static __global__ __launch_bounds__(SORT_BLK) void k_sort_scan(uint32_t *__restr
     if (threadIdx.x == 0) totals[blockIdx.x] = tot;
 }
 
-template <class K>
+template <class K, int ITEMS>
 __global__ __launch_bounds__(SORT_BLK) void k_sort_scatter(const K *__restrict__ keys, const uint32_t *__restrict__ vals, int64_t n, int shift, uint32_t mask, int bits,
                                                           const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals, int ntiles, K *__restrict__ keys_out,
                                                           uint32_t *__restrict__ vals_out)
 {
-    __shared__ K skeys[SORT_TILE];
-    __shared__ uint32_t svals[SORT_TILE];
+    constexpr int TILE = SORT_BLK * ITEMS;
+    __shared__ K skeys[TILE];
+    __shared__ uint32_t svals[TILE];
     __shared__ uint32_t wrun[SORT_WAVES][256]; // first the wave's digit counts, then its running positions
     __shared__ uint32_t goff[256];             // global position of local position 0 of each digit's run (may wrap: uint arithmetic)
     __shared__ uint32_t sh[SORT_WAVES];
     const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = (int)blockIdx.x;
-    const int64_t base = (int64_t)tile * SORT_TILE + (int64_t)w * (SORT_TILE / SORT_WAVES);
+    const int64_t base = (int64_t)tile * TILE + (int64_t)w * (TILE / SORT_WAVES);
 #pragma unroll
     for (int k = 0; k < SORT_WAVES; ++k) wrun[k][tid] = 0u;
     __syncthreads();
-    K key[SORT_ITEMS];
-    uint32_t val[SORT_ITEMS];
+    K key[ITEMS];
+    uint32_t val[ITEMS];
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = base + r * 64 + lane;
         const bool in = i < n;
         key[r] = in ? keys[i] : (K)0;
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_scatter(const K *__restrict__
     __syncthreads();
     // stable ranking, wave-private
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = base + r * 64 + lane;
         const bool in = i < n;
         const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
@@ -146,9 +152,9 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_scatter(const K *__restrict__
         if (in) { skeys[pos] = key[r]; svals[pos] = val[r]; }
     }
     __syncthreads();
-    const int64_t tile_n = min((int64_t)SORT_TILE, n - (int64_t)tile * SORT_TILE);
+    const int64_t tile_n = min((int64_t)TILE, n - (int64_t)tile * TILE);
 #pragma unroll
-    for (int it = 0; it < SORT_ITEMS; ++it) {
+    for (int it = 0; it < ITEMS; ++it) {
         const int j = it * SORT_BLK + tid;
         if (j < tile_n) {
             const K k = skeys[j];
@@ -270,7 +276,8 @@ int radix_sort_pairs(sf_ctx *ctx, K *keys, K *keys_alt, uint32_t *vals, uint32_t
     if (n <= 1 || end_bit == 0) return SF_OK;
     SF_CHECK(n < (int64_t)0xffffffffll, SF_ERR_OVERFLOW, "radix sort: more than 2^32 - 1 elements");
     const int passes = (int)((end_bit + 7) / 8), bits = (int)((end_bit + passes - 1) / passes);
-    const int ntiles = (int)div_up(n, SORT_TILE);
+    const bool small = n < SORT_SMALL_N;
+    const int ntiles = (int)div_up(n, small ? SORT_BLK * SORT_ITEMS_SMALL : SORT_TILE);
     const uint32_t mask = (1u << bits) - 1u;
     SF_TRY(ctx->sort_hist.reserve(sizeof(uint32_t) * ((size_t)(mask + 1) * (size_t)ntiles + 256)));
     uint32_t *hist = ctx->sort_hist.as<uint32_t>(), *totals = hist + (size_t)(mask + 1) * (size_t)ntiles;
@@ -279,9 +286,11 @@ int radix_sort_pairs(sf_ctx *ctx, K *keys, K *keys_alt, uint32_t *vals, uint32_t
     uint32_t *va = vals, *vb = vals_alt;
     for (int p = 0; p < passes; ++p) {
         const int shift = p * bits;
-        hipLaunchKernelGGL((k_sort_hist<K>), dim3((unsigned)ntiles), dim3(SORT_BLK), 0, st, ka, n, shift, mask, hist, ntiles);
+        if (small) hipLaunchKernelGGL((k_sort_hist<K, SORT_ITEMS_SMALL>), dim3((unsigned)ntiles), dim3(SORT_BLK), 0, st, ka, n, shift, mask, hist, ntiles);
+        else hipLaunchKernelGGL((k_sort_hist<K, SORT_ITEMS>), dim3((unsigned)ntiles), dim3(SORT_BLK), 0, st, ka, n, shift, mask, hist, ntiles);
         hipLaunchKernelGGL(k_sort_scan, dim3(mask + 1), dim3(SORT_BLK), 0, st, hist, ntiles, totals);
-        hipLaunchKernelGGL((k_sort_scatter<K>), dim3((unsigned)ntiles), dim3(SORT_BLK), 0, st, ka, va, n, shift, mask, bits, hist, totals, ntiles, kb, vb);
+        if (small) hipLaunchKernelGGL((k_sort_scatter<K, SORT_ITEMS_SMALL>), dim3((unsigned)ntiles), dim3(SORT_BLK), 0, st, ka, va, n, shift, mask, bits, hist, totals, ntiles, kb, vb);
+        else hipLaunchKernelGGL((k_sort_scatter<K, SORT_ITEMS>), dim3((unsigned)ntiles), dim3(SORT_BLK), 0, st, ka, va, n, shift, mask, bits, hist, totals, ntiles, kb, vb);
         K *tk = ka; ka = kb; kb = tk;
         uint32_t *tv = va; va = vb; vb = tv;
     }

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstring>
 
 namespace {
 
@@ -273,16 +274,46 @@ int download_i32(sf_cloud *c, const sf::DevBuf &buf, int64_t have, int32_t *dst,
 // new voxels.  The result is bit-identical to the full path (tests/test_gpu_map_growth.py, test_gpu_config4_stream.py).
 namespace {
 
-__global__ void k_check_ascending(const uint32_t *__restrict__ keys, int64_t n, uint32_t *__restrict__ bad)
+__device__ __forceinline__ uint32_t pcl_key_u32(const PclGeom &g, float x, float y, float z)
+{
+    // (k_pcl_keys for a finite point)
+    const int i0 = (int)(floorf(__fmul_rn(x, g.inv)) - (float)g.min_b[0]);
+    const int i1 = (int)(floorf(__fmul_rn(y, g.inv)) - (float)g.min_b[1]);
+    const int i2 = (int)(floorf(__fmul_rn(z, g.inv)) - (float)g.min_b[2]);
+    return (uint32_t)(i0 * (int)g.mul[0] + i1 * (int)g.mul[1] + i2 * (int)g.mul[2]);
+}
+
+// the old (filtered, finite) points: keys under the union's geometry, which must be strictly ascending -- one pass, keys only
+__global__ __launch_bounds__(256) void k_merge_old_keys(const float *__restrict__ xyz, int64_t n, PclGeom g, uint32_t *__restrict__ keys, uint32_t *__restrict__ bad)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > 0 && j < n && keys[j] <= keys[j - 1]) *bad = 1u;
+    if (j >= n) return;
+    const uint32_t k = pcl_key_u32(g, xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]);
+    keys[j] = k;
+    uint32_t prev = __shfl_up(k, 1, 64);
+    if ((threadIdx.x & 63) == 0 && j > 0) prev = pcl_key_u32(g, xyz[3 * j - 3], xyz[3 * j - 2], xyz[3 * j - 1]);
+    if (j > 0 && k <= prev) *bad = 1u;
+}
+
+// coarse[b] = number of fresh voxels whose rank is below 64 b: old point j moves up by coarse[j / 64] plus the few in its own 64
+__global__ void k_merge_coarse(const uint32_t *__restrict__ fresh_rank, int64_t n_fresh, int64_t n_coarse, uint32_t *__restrict__ coarse)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_coarse) return;
+    const uint64_t v = (uint64_t)b * 64u;
+    int64_t lo = 0, hi = n_fresh;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)fresh_rank[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    coarse[b] = (uint32_t)lo;
 }
 
 // one lane per voxel of the pending points: where it goes in the old map and its centroid
 __global__ void k_merge_groups(const float *__restrict__ old_xyz, const uint32_t *__restrict__ old_keys, int64_t n_old, const float *__restrict__ new_xyz,
                                const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos,
-                               int64_t m_valid, uint32_t *__restrict__ g_rank, uint32_t *__restrict__ g_fresh, float *__restrict__ g_centroid)
+                               int64_t m_valid, uint32_t *__restrict__ g_rank, uint32_t *__restrict__ g_fresh, float *__restrict__ g_centroid, float *__restrict__ g_old)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m_valid || !flags[j]) return;
@@ -300,6 +331,7 @@ __global__ void k_merge_groups(const float *__restrict__ old_xyz, const uint32_t
         sx = __fadd_rn(sx, old_xyz[3 * lo]); sy = __fadd_rn(sy, old_xyz[3 * lo + 1]); sz = __fadd_rn(sz, old_xyz[3 * lo + 2]);
         cnt = 1;
     }
+    const float ox = sx, oy = sy, oz = sz; // (0 + x = x: the old point itself, for sf_map_patch)
     for (int64_t k = j; k < m_valid && keys[k] == key; ++k) {
         const size_t p = vals[k];
         sx = __fadd_rn(sx, new_xyz[3 * p]); sy = __fadd_rn(sy, new_xyz[3 * p + 1]); sz = __fadd_rn(sz, new_xyz[3 * p + 2]);
@@ -310,6 +342,57 @@ __global__ void k_merge_groups(const float *__restrict__ old_xyz, const uint32_t
     g_rank[g] = (uint32_t)lo;
     g_fresh[g] = found ? 0u : 1u;
     g_centroid[3 * g] = __fdiv_rn(sx, c); g_centroid[3 * g + 1] = __fdiv_rn(sy, c); g_centroid[3 * g + 2] = __fdiv_rn(sz, c);
+    g_old[3 * g] = ox; g_old[3 * g + 1] = oy; g_old[3 * g + 2] = oz;
+}
+
+__device__ __forceinline__ int float_ordered(float f)
+{
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+inline float float_from_ordered(int o)
+{
+    const int i = o >= 0 ? o : o ^ 0x7fffffff;
+    float f;
+    memcpy(&f, &i, sizeof(f));
+    return f;
+}
+
+struct MergeExtremes { int mn[3], mx[3]; uint32_t touched_extreme, pad; };
+
+// bounds of the centroids; does a replaced old point hold one of the map's bounds?  (a few workgroups, grid-stride: the six
+// atomics per workgroup all land on one cache line)
+__global__ __launch_bounds__(256) void k_merge_extremes(const uint32_t *__restrict__ g_fresh, const float *__restrict__ g_centroid, const float *__restrict__ g_old, int64_t n_groups,
+                                                         float mnx, float mny, float mnz, float mxx, float mxy, float mxz, MergeExtremes *__restrict__ out)
+{
+    __shared__ int s_lo[4][3], s_hi[4][3];
+    int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    bool touched = false;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int o = float_ordered(g_centroid[3 * g + d]);
+            lo[d] = min(lo[d], o);
+            hi[d] = max(hi[d], o);
+        }
+        if (!g_fresh[g]) {
+            const float px = g_old[3 * g], py = g_old[3 * g + 1], pz = g_old[3 * g + 2];
+            touched |= px <= mnx || py <= mny || pz <= mnz || px >= mxx || py >= mxy || pz >= mxz;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) { lo[d] = min(lo[d], __shfl_xor(lo[d], s, 64)); hi[d] = max(hi[d], __shfl_xor(hi[d], s, 64)); }
+        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6][d] = lo[d]; s_hi[threadIdx.x >> 6][d] = hi[d]; }
+    }
+    if (touched) out->touched_extreme = 1u;
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        atomicMin(&out->mn[d], min(min(s_lo[0][d], s_lo[1][d]), min(s_lo[2][d], s_lo[3][d])));
+        atomicMax(&out->mx[d], max(max(s_hi[0][d], s_hi[1][d]), max(s_hi[2][d], s_hi[3][d])));
+    }
 }
 
 // the ranks of the fresh voxels, compacted (ascending, since the groups are)
@@ -321,31 +404,15 @@ __global__ void k_merge_fresh_ranks(const uint32_t *__restrict__ g_rank, const u
 }
 
 // old point j moves up by the number of fresh voxels that sort before it (fresh_rank <= j)
-__global__ __launch_bounds__(256) void k_merge_copy(const float *__restrict__ old_xyz, int64_t n_old, const uint32_t *__restrict__ fresh_rank, int64_t n_fresh,
+__global__ __launch_bounds__(256) void k_merge_copy(const float *__restrict__ old_xyz, int64_t n_old, const uint32_t *__restrict__ fresh_rank, const uint32_t *__restrict__ coarse,
                                                      float *__restrict__ out)
 {
-    __shared__ int64_t lo_s, hi_s;
-    const int64_t j0 = (int64_t)blockIdx.x * blockDim.x, j = j0 + threadIdx.x;
-    if (threadIdx.x < 2) { // upper_bound(fresh_rank, j0 - 1 .. j0 + 255): the block's range of candidates
-        const int64_t v = threadIdx.x == 0 ? j0 - 1 : j0 + (int64_t)blockDim.x - 1;
-        int64_t lo = 0, hi = n_fresh;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if ((int64_t)fresh_rank[mid] <= v) lo = mid + 1;
-            else hi = mid;
-        }
-        if (threadIdx.x == 0) lo_s = lo;
-        else hi_s = lo;
-    }
-    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_old) return;
-    int64_t lo = lo_s, hi = hi_s;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)fresh_rank[mid] <= j) lo = mid + 1;
-        else hi = mid;
-    }
-    const size_t d = (size_t)(j + lo);
+    uint32_t f = coarse[j >> 6];
+    const uint32_t f_end = coarse[(j >> 6) + 1];
+    while (f < f_end && (int64_t)fresh_rank[f] <= j) ++f;
+    const size_t d = (size_t)j + (size_t)f;
     out[3 * d] = old_xyz[3 * j]; out[3 * d + 1] = old_xyz[3 * j + 1]; out[3 * d + 2] = old_xyz[3 * j + 2];
 }
 
@@ -383,6 +450,8 @@ extern "C" int sf_cloud_voxel_merge(sf_cloud *map, sf_cloud *pending, double lea
     hipStream_t st = ctx->stream;
     const int64_t n = map->n, m = pending->n;
     const float leaf = (float)leaf_d, inv = 1.0f / leaf;
+    const uint64_t stamp_before = map->stamp;
+    if (m > 0) sf::cloud_touch(map); // (an empty pending cloud leaves the filtered map as it is)
     auto full_path = [&]() -> int {
         SF_TRY(sf_cloud_append(map, pending));
         return sf_cloud_voxel_downsample(map, leaf_d, SF_VOXEL_PCL, status_flags);
@@ -392,16 +461,23 @@ extern "C" int sf_cloud_voxel_merge(sf_cloud *map, sf_cloud *pending, double lea
     // geometry of the union, as pcl::VoxelGrid computes it over the concatenated cloud
     // (both reductions enqueued, ONE synchronisation: on a map of a few million points the merge is bound by its host round trips)
     sf::DevBuf &mt = ctx->merge_tmp;
-    SF_TRY(mt.reserve(sizeof(uint32_t) * 4 * (size_t)m + sizeof(float) * 3 * (size_t)m + 64 + 2 * sizeof(sf::MinMaxDev)));
-    sf::MinMaxDev *d_mm = reinterpret_cast<sf::MinMaxDev *>(mt.as<unsigned char>() + sizeof(uint32_t) * 4 * (size_t)m + sizeof(float) * 3 * (size_t)m + 64);
-    SF_TRY(sf::cloud_minmax_enqueue(ctx, map->xyz.as<float>(), n, d_mm));
+    const int64_t n_coarse = n / 64 + 2;
+    SF_TRY(mt.reserve(sizeof(uint32_t) * 4 * (size_t)m + sizeof(float) * 6 * (size_t)m + 64 + 2 * sizeof(sf::MinMaxDev) + sizeof(uint32_t) * (size_t)n_coarse));
+    sf::MinMaxDev *d_mm = reinterpret_cast<sf::MinMaxDev *>(mt.as<unsigned char>() + sizeof(uint32_t) * 4 * (size_t)m + sizeof(float) * 6 * (size_t)m + 64);
+    uint32_t *coarse = reinterpret_cast<uint32_t *>(d_mm + 2);
+    const bool know_bounds = stamp_before != 0 && map->bounds_stamp == stamp_before; // (left behind by the previous merge: all points finite)
+    if (!know_bounds) SF_TRY(sf::cloud_minmax_enqueue(ctx, map->xyz.as<float>(), n, d_mm));
     {
         sf::MinMaxDev h_a;
-        SF_HIP(hipMemcpyAsync(&h_a, d_mm, sizeof(h_a), hipMemcpyDeviceToHost, st)); // (the partial buffer of the reduction is reused by the next one: stream order)
+        if (!know_bounds) SF_HIP(hipMemcpyAsync(&h_a, d_mm, sizeof(h_a), hipMemcpyDeviceToHost, st)); // (the partial buffer of the reduction is reused by the next one: stream order)
         SF_TRY(sf::cloud_minmax_enqueue(ctx, pending->xyz.as<float>(), m, d_mm + 1));
         sf::MinMaxDev h_b;
         SF_HIP(hipMemcpyAsync(&h_b, d_mm + 1, sizeof(h_b), hipMemcpyDeviceToHost, st));
         SF_HIP(hipStreamSynchronize(st));
+        if (know_bounds) {
+            for (int d = 0; d < 3; ++d) { h_a.mn[d] = map->bounds_mn[d]; h_a.mx[d] = map->bounds_mx[d]; }
+            h_a.cnt = (unsigned long long)n;
+        }
         mm_a = h_a;
         mm_b = h_b;
     }
@@ -435,16 +511,17 @@ extern "C" int sf_cloud_voxel_merge(sf_cloud *map, sf_cloud *pending, double lea
     SF_TRY(pos.reserve(sizeof(uint32_t) * (size_t)(n + 2 * m)));
     // per group: rank, fresh flag, fresh prefix, fresh ranks, centroid; + the "keys not ascending" flag (mt reserved above)
     uint32_t *g_rank = mt.as<uint32_t>(), *g_fresh = g_rank + m, *fresh_pos = g_fresh + m, *fresh_rank = fresh_pos + m;
-    float *g_centroid = reinterpret_cast<float *>(fresh_rank + m);
-    uint32_t *bad = reinterpret_cast<uint32_t *>(g_centroid + 3 * m);
-    SF_TRY(map->vox_point_ids.reserve(sizeof(int32_t) * (size_t)(n + m))); // (the key kernel writes per-point ids: scratch here)
+    ++ctx->merge_epoch;
+    float *g_centroid = reinterpret_cast<float *>(fresh_rank + m), *g_old = g_centroid + 3 * m;
+    uint32_t *bad = reinterpret_cast<uint32_t *>(g_old + 3 * m);
+    MergeExtremes *d_ext = reinterpret_cast<MergeExtremes *>(bad + 4); // (inside the 64 spare bytes)
+    SF_TRY(map->vox_point_ids.reserve(sizeof(int32_t) * (size_t)m)); // (the key kernel writes per-point ids: scratch here)
     SF_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), st));
-    // old points: keys under the union's geometry, must be strictly ascending
-    hipLaunchKernelGGL((k_pcl_keys<uint32_t, int32_t>), dim3(nblk(n)), dim3(256), 0, st, map->xyz.as<float>(), n, g, old_keys.as<uint32_t>(), vals2.as<uint32_t>(), map->vox_point_ids.as<int32_t>());
-    hipLaunchKernelGGL(k_check_ascending, dim3(nblk(n)), dim3(256), 0, st, old_keys.as<uint32_t>(), n, bad);
+    // old points (all finite, checked above): keys under the union's geometry, must be strictly ascending
+    hipLaunchKernelGGL(k_merge_old_keys, dim3(nblk(n)), dim3(256), 0, st, map->xyz.as<float>(), n, g, old_keys.as<uint32_t>(), bad);
     // pending points: keys, stable sort, voxel heads
     uint32_t *nk = keys.as<uint32_t>(), *nk2 = nk + m, *nv = vals.as<uint32_t>(), *nv2 = nv + m;
-    hipLaunchKernelGGL((k_pcl_keys<uint32_t, int32_t>), dim3(nblk(m)), dim3(256), 0, st, pending->xyz.as<float>(), m, g, nk, nv, map->vox_point_ids.as<int32_t>() + n);
+    hipLaunchKernelGGL((k_pcl_keys<uint32_t, int32_t>), dim3(nblk(m)), dim3(256), 0, st, pending->xyz.as<float>(), m, g, nk, nv, map->vox_point_ids.as<int32_t>());
     uint32_t *sk = nullptr, *sv = nullptr;
     SF_TRY(sf::radix_sort_pairs<uint32_t>(ctx, nk, nk2, nv, nv2, m, end_bit, &sk, &sv));
     int64_t n_groups = 0;
@@ -453,23 +530,48 @@ extern "C" int sf_cloud_voxel_merge(sf_cloud *map, sf_cloud *pending, double lea
     SF_TRY(scan_heads<uint32_t>(ctx, sk, b.n_finite, flags.as<uint32_t>(), pos.as<uint32_t>(), &n_groups));
     if (*h_flag) return full_path();
     hipLaunchKernelGGL(k_merge_groups, dim3(nblk(b.n_finite)), dim3(256), 0, st, map->xyz.as<float>(), old_keys.as<uint32_t>(), n, pending->xyz.as<float>(), sk, sv, flags.as<uint32_t>(),
-                       pos.as<uint32_t>(), b.n_finite, g_rank, g_fresh, g_centroid);
+                       pos.as<uint32_t>(), b.n_finite, g_rank, g_fresh, g_centroid, g_old);
     SF_TRY(sf::scan_u32<0>(ctx, g_fresh, fresh_pos, n_groups));
     uint32_t *h = reinterpret_cast<uint32_t *>(ctx->h_pinned);
+    MergeExtremes *h_ext = reinterpret_cast<MergeExtremes *>(static_cast<unsigned char *>(ctx->h_pinned) + 128);
+    for (int d = 0; d < 3; ++d) { h_ext->mn[d] = INT32_MAX; h_ext->mx[d] = INT32_MIN; }
+    h_ext->touched_extreme = h_ext->pad = 0u;
+    SF_HIP(hipMemcpyAsync(d_ext, h_ext, sizeof(MergeExtremes), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_merge_extremes, dim3((unsigned)std::min<int64_t>(64, nblk(n_groups))), dim3(256), 0, st, g_fresh, g_centroid, g_old, n_groups, a.mn[0], a.mn[1], a.mn[2],
+                       a.mx[0], a.mx[1], a.mx[2], d_ext);
     SF_HIP(hipMemcpyAsync(h, fresh_pos + (n_groups - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SF_HIP(hipMemcpyAsync(h + 1, g_fresh + (n_groups - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SF_HIP(hipMemcpyAsync(h_ext, d_ext, sizeof(MergeExtremes), hipMemcpyDeviceToHost, st));
     SF_HIP(hipStreamSynchronize(st));
     const int64_t n_fresh = (int64_t)h[0] + (int64_t)h[1], n_out = n + n_fresh;
     sf::DevBuf &out = map->spare;
     SF_TRY(out.reserve(sizeof(float) * 3 * (size_t)n_out));
     hipLaunchKernelGGL(k_merge_fresh_ranks, dim3(nblk(n_groups)), dim3(256), 0, st, g_rank, g_fresh, fresh_pos, n_groups, fresh_rank);
-    hipLaunchKernelGGL(k_merge_copy, dim3(nblk(n)), dim3(256), 0, st, map->xyz.as<float>(), n, fresh_rank, n_fresh, out.as<float>());
+    hipLaunchKernelGGL(k_merge_coarse, dim3(nblk(n_coarse)), dim3(256), 0, st, fresh_rank, n_fresh, n_coarse, coarse);
+    hipLaunchKernelGGL(k_merge_copy, dim3(nblk(n)), dim3(256), 0, st, map->xyz.as<float>(), n, fresh_rank, coarse, out.as<float>());
     hipLaunchKernelGGL(k_merge_place, dim3(nblk(n_groups)), dim3(256), 0, st, g_rank, g_fresh, fresh_pos, g_centroid, n_groups, out.as<float>());
     SF_HIP(hipGetLastError());
     map->xyz.swap(out);
     map->n = n_out;
     map->n_last_idx = -1;
     map->n_vox_point_vals = map->n_vox_out_vals = map->n_vox_out_pts = 0; // (per-point / per-voxel ids are those of a full pass only)
+    // what sf_map_patch needs to carry an index of the old map over to the new one
+    sf_cloud::MergeRecord &rec = map->merge;
+    rec.valid = true;
+    rec.epoch = ctx->merge_epoch;
+    rec.stamp_before = stamp_before;
+    rec.stamp_after = map->stamp;
+    rec.n_old = n; rec.n_groups = n_groups; rec.n_fresh = n_fresh;
+    rec.g_rank = g_rank; rec.g_fresh = g_fresh; rec.fresh_pos = fresh_pos; rec.fresh_rank = fresh_rank; rec.g_centroid = g_centroid; rec.g_old = g_old; rec.coarse = coarse;
+    rec.touched_extreme = h_ext->touched_extreme != 0;
+    for (int d = 0; d < 3; ++d) {
+        rec.old_mn[d] = a.mn[d]; rec.old_mx[d] = a.mx[d];
+        rec.cen_mn[d] = float_from_ordered(h_ext->mn[d]); rec.cen_mx[d] = float_from_ordered(h_ext->mx[d]);
+    }
+    if (!rec.touched_extreme) { // every old point that held a bound is still there: the bounds of the merged map are known
+        for (int d = 0; d < 3; ++d) { map->bounds_mn[d] = std::min(a.mn[d], rec.cen_mn[d]); map->bounds_mx[d] = std::max(a.mx[d], rec.cen_mx[d]); }
+        map->bounds_stamp = map->stamp;
+    }
     if (merged) *merged = 1;
     return SF_OK;
 }
@@ -480,6 +582,7 @@ extern "C" int sf_cloud_voxel_downsample(sf_cloud *c, double leaf, int flavour, 
     SF_CHECK(flavour == SF_VOXEL_PCL || flavour == SF_VOXEL_O3D || flavour == SF_VOXEL_PCL64, SF_ERR_INVALID, "unknown voxel flavour %d", flavour);
     SF_HIP(hipSetDevice(c->ctx->device));
     if (status_flags) *status_flags = 0;
+    sf::cloud_touch(c);
     c->n_vox_point_vals = c->n_vox_out_vals = c->n_vox_out_pts = 0;
     if (c->n == 0) return SF_OK;
     if (flavour == SF_VOXEL_PCL) return voxel_pcl<uint32_t, int32_t>(c, (float)leaf, status_flags);

@@ -320,6 +320,7 @@ class ImuEkfMappingFlow(EkfLocalizationFlow):
         self.scans_since_growth_ = 0
         self.growths_ = 0
         self.merges_ = 0                                      # growth steps that took the merge path of sf_cloud_voxel_merge
+        self.patches_ = 0                                     # ... and whose index was merged from the old one (sf_map_patch)
         self.on_grow = None                                   # test hook: on_grow(flow) just before a growth step
 
     def pose_prior(self, gps, odom, odom_T_sensor_current):
@@ -367,11 +368,15 @@ class ImuEkfMappingFlow(EkfLocalizationFlow):
             self.map_full_.append(self.pending_)
             self.map_full_.voxel_downsample(self.voxel_, self.voxel_flavour_)
         if self.index_stride_ == 1:                           # the index is built straight from the voxel-filtered map (it copies what it needs)
-            self.index_cloud_ = self.map_full_
+            if self.index_cloud_ is self.map_full_:           # ... and carried over the growth step when it indexed this very cloud before the merge
+                self.patches_ += int(self.map_index_.patch(self.map_full_))
+            else:
+                self.index_cloud_ = self.map_full_
+                self.map_index_.build(self.index_cloud_, 0.0)
         else:
             self.index_cloud_.copy_from(self.map_full_)
             self.index_cloud_.subsample(self.index_stride_)
-        self.map_index_.build(self.index_cloud_, 0.0)
+            self.map_index_.build(self.index_cloud_, 0.0)
         self.map_cloud_ = self.index_cloud_
         self.icp_.set_target(self.map_index_)
         self.have_window_ = False                             # the rebuilt index has no window yet: set at the next scan

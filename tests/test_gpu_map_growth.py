@@ -113,3 +113,119 @@ def test_voxel_merge_equals_append_plus_filter(api, ctx, orc, synth):
     api.voxel_merge_min_points(prev)
     st, merged = dev.voxel_merge(api.Cloud(ctx, steps[2]), 0.1)       # below the default threshold: the full path, same semantics
     assert st == 0 and not merged
+
+
+def _same_index(a, b):
+    for k in ("pts4", "cell_start", "org"):
+        if a[k].shape != b[k].shape or not np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)):
+            return k
+    if a["inv_h"] != b["inv_h"] or a["gap_eps"] != b["gap_eps"]:
+        return "scalars"
+    return ""
+
+
+def test_index_patch_equals_rebuild(api, ctx, synth):
+    """sf_map_patch == sf_map_build of the merged cloud with the same cell (points in cell order with their ids, cell table,
+    geometry: bit for bit) over growth steps that touch voxels, open new ones inside and beyond the map's
+    upper faces (the grid gets more cells per row: every cell id changes, the order does not), and the cases that must
+    take the build: the smallest coordinate moves, the cloud was changed between merge and patch, the merge took its full
+    path, the index is of another cloud.  setTargetPointCloud after `*map_cloud += *cloud` + VoxelGrid:
+    icp_point_to_point.cpp:49-55, global_map_frames_manager.cpp:131,142-146."""
+    rng = np.random.default_rng(9)
+    prev = api.voxel_merge_min_points(0)
+    try:
+        base = synth.make_map(400_000)                                # 20 m x 20 m x 10 m
+        inner = base[(np.abs(base[:, 0]) < 6.0) & (np.abs(base[:, 1]) < 6.0)]
+        dev = api.Cloud(ctx, inner)
+        dev.voxel_downsample(0.1, "pcl")
+        lo, hi = dev.download().min(0), dev.download().max(0)
+        for cell in (0.25, 0.0):                                      # an explicit cell, and the one the build chooses itself
+            dev = api.Cloud(ctx, inner)
+            dev.voxel_downsample(0.1, "pcl")
+            mp = api.Map(ctx, dev, cell)
+            h, dims0 = mp.cell_size()
+            core = inner[(np.abs(inner[:, 0]) < 5.5) & (np.abs(inner[:, 1]) < 5.5) & (np.abs(inner[:, 2]) < 4.5)]    # (away from the points that hold the map's extremes)
+            near = lambda n: (core[rng.choice(len(core), n, replace=False)] + rng.normal(0, 0.004, (n, 3))).astype(np.float32)
+
+            def top():                                                # the point that holds the largest y right now
+                pts = dev.download()
+                return pts[np.argmax(pts[:, 1])]
+            steps = [("touch + fill", near(30_000), True),
+                     ("beyond +x / +y / +z", np.concatenate([near(5_000), (rng.uniform(0, 1, (20_000, 3)) * (hi - lo + [3.0, 2.0, 1.0]) + lo + 0.01).astype(np.float32)]), True),
+                     ("duplicates", np.repeat(near(200), 30, axis=0), True),
+                     ("an extreme point is replaced", lambda: np.concatenate([near(1_000), (top() - np.float32(0.001))[None]]), False),
+                     ("below the origin", np.concatenate([near(1_000), (lo - [0.5, 0.0, 0.0]).astype(np.float32)[None]]), False)]
+            for name, add, expect in steps:
+                add = add() if callable(add) else add
+                st, merged = dev.voxel_merge(api.Cloud(ctx, add), 0.1)
+                assert st == 0 and merged, name
+                patched = mp.patch(dev)
+                assert patched == expect, (name, cell)
+                ref = api.Map(ctx, dev, h)
+                assert _same_index(mp.index(), ref.index()) == "", (name, cell, _same_index(mp.index(), ref.index()))
+                assert mp.cell_size() == ref.cell_size() and len(mp) == len(ref) == len(dev)
+                if name.startswith("beyond"):
+                    assert mp.cell_size()[1] != dims0                 # more cells per row: the patch renumbered them
+            # the patched index answers like the rebuilt one
+            q = (dev.download()[rng.choice(len(dev), 20_000)] + rng.normal(0, 0.05, (20_000, 3))).astype(np.float32)
+            ia, da = mp.nn(q, 0.25)
+            ib, db = ref.nn(q, 0.25)
+            assert np.array_equal(ia, ib) and np.array_equal(da, db)
+            # the cloud changes between merge and patch: nothing of the merge may be trusted
+            st, merged = dev.voxel_merge(api.Cloud(ctx, near(5_000)), 0.1)
+            assert merged
+            dev.transform(np.eye(4, dtype=np.float32))
+            assert not mp.patch(dev)
+            assert _same_index(mp.index(), api.Map(ctx, dev, h).index()) == ""
+            # a merge that took the full path (pending empty), then a good one again
+            dev.voxel_merge(api.Cloud(ctx, np.zeros((0, 3), np.float32)), 0.1)
+            assert not mp.patch(dev)
+            st, merged = dev.voxel_merge(api.Cloud(ctx, near(5_000)), 0.1)
+            assert merged and mp.patch(dev)
+            assert _same_index(mp.index(), api.Map(ctx, dev, h).index()) == ""
+            # an index of another cloud, and a merge of another cloud in between (the merge tables are the context's)
+            other = api.Cloud(ctx, dev.download()[::2].copy())
+            other.voxel_downsample(0.1, "pcl")
+            mo = api.Map(ctx, other, h)
+            st, merged = dev.voxel_merge(api.Cloud(ctx, near(3_000)), 0.1)
+            assert merged and not mo.patch(dev)
+            assert _same_index(mo.index(), api.Map(ctx, dev, h).index()) == ""
+            mp.build(dev, h)
+            st, merged = dev.voxel_merge(api.Cloud(ctx, near(3_000)), 0.1)
+            st2, merged2 = other.voxel_merge(api.Cloud(ctx, near(2_000)), 0.1)
+            assert merged and merged2 and not mp.patch(dev)
+            assert _same_index(mp.index(), api.Map(ctx, dev, h).index()) == ""
+    finally:
+        api.voxel_merge_min_points(prev)
+
+
+def test_index_patch_registration_identical(api, ctx, synth):
+    """A registration against the patched index equals one against the rebuilt index, bit for bit, normals re-estimated on both."""
+    rng = np.random.default_rng(10)
+    prev = api.voxel_merge_min_points(0)
+    try:
+        base = synth.make_map(300_000)
+        dev = api.Cloud(ctx, base[base[:, 0] < 2.0])
+        dev.voxel_downsample(0.1, "pcl")
+        mp = api.Map(ctx, dev, 0.25)
+        add = base[(base[:, 0] >= 1.0) & ((base[:, 0] < 1.8) | (base[:, 0] >= 2.0)) & (base[:, 0] < 6.0) & (np.abs(base[:, 1]) < 8.0) & (np.abs(base[:, 2]) < 4.5)]
+        add = (add + np.float32(0.003)).astype(np.float32)               # (towards +x only, the points that hold the map's extremes left alone: the origin stays)
+        st, merged = dev.voxel_merge(api.Cloud(ctx, add), 0.1)
+        assert merged and mp.patch(dev)
+        ref = api.Map(ctx, dev, 0.25)
+        ds = dev.download()
+        scan, _ = synth.make_scan(ds[(ds[:, 0] > 0.0) & (ds[:, 0] < 5.0)], 20_000)
+        out = []
+        for m in (mp, ref):
+            m.estimate_normals(0.25)
+            icp = api.Icp(ctx, 0.5, 20, 0.05, 1e-5)
+            icp.set_target(m)
+            icp.set_source(scan)
+            out.append([icp.align(mode) for mode in ("ref_cpp", "o3d_p2p", "p2plane")])
+            icp.close()
+        for a, b in zip(*out):
+            assert np.array_equal(a["T64"], b["T64"]) and a["iterations"] == b["iterations"] and a["fitness"] == b["fitness"]
+        na, nb = mp.download_normals(), ref.download_normals()
+        assert np.array_equal(na[0], nb[0]) and np.array_equal(na[1], nb[1])
+    finally:
+        api.voxel_merge_min_points(prev)
