@@ -11,7 +11,8 @@
 //   k_sort_scan     one workgroup per digit: exclusive prefix of its row over the tiles, the row total aside;
 //                   the 256 totals are prefixed by the scatter itself (one wave)
 //   k_sort_scatter  a workgroup reads its tile once (keys and values stay in registers), ranks it stably and moves it
-//                   through LDS into digit order, then writes runs of equal digits to consecutive addresses.
+//                   through LDS into digit order -- the keys, then the values through the same storage --, then writes
+//                   runs of equal digits to consecutive addresses.  Tiles are dealt to the XCDs in contiguous eighths.
 // Ranking: wave w owns the contiguous quarter w of the tile; in each of its 16 rounds the 64 lanes find the lanes
 // with the same digit by one ballot per digit bit (rank = popcount of the lower ones), add the wave's running count of
 // that digit (LDS, wave-private: no workgroup barrier inside the loop) and the first lane of each group advances the
@@ -30,18 +31,37 @@ constexpr int64_t SORT_SMALL_N = 1 << 20;
 template <class K, int ITEMS>
 __global__ __launch_bounds__(SORT_BLK) void k_sort_hist(const K *__restrict__ keys, int64_t n, int shift, uint32_t mask, uint32_t *__restrict__ hist, int ntiles)
 {
-    constexpr int TILE = SORT_BLK * ITEMS;
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0u;
+    constexpr int TILE = SORT_BLK * ITEMS, PER = 16 / (int)sizeof(K); // PER keys per 16-byte load
+    __shared__ uint32_t h[SORT_WAVES][256];                          // wave-private counts: a quarter of the collisions
+#pragma unroll
+    for (int k = 0; k < SORT_WAVES; ++k) h[k][threadIdx.x] = 0u;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * TILE;
+    uint32_t *mine = h[threadIdx.x >> 6];
+    if (base + TILE <= n && (reinterpret_cast<uintptr_t>(keys + base) & 15u) == 0u) { // a full, aligned tile: 16 bytes per lane and load
+        const uint4 *src = reinterpret_cast<const uint4 *>(keys + base);
+        uint4 v[ITEMS / PER];
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const int64_t i = base + it * SORT_BLK + (int)threadIdx.x;
-        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
+        for (int it = 0; it < ITEMS / PER; ++it) v[it] = src[it * SORT_BLK + (int)threadIdx.x];
+#pragma unroll
+        for (int it = 0; it < ITEMS / PER; ++it) {
+            if (sizeof(K) == 4) {
+                atomicAdd(&mine[(v[it].x >> shift) & mask], 1u); atomicAdd(&mine[(v[it].y >> shift) & mask], 1u);
+                atomicAdd(&mine[(v[it].z >> shift) & mask], 1u); atomicAdd(&mine[(v[it].w >> shift) & mask], 1u);
+            } else {
+                const uint64_t k0 = ((uint64_t)v[it].y << 32) | v[it].x, k1 = ((uint64_t)v[it].w << 32) | v[it].z;
+                atomicAdd(&mine[(uint32_t)(k0 >> shift) & mask], 1u); atomicAdd(&mine[(uint32_t)(k1 >> shift) & mask], 1u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int64_t i = base + it * SORT_BLK + (int)threadIdx.x;
+            if (i < n) atomicAdd(&mine[(uint32_t)(keys[i] >> shift) & mask], 1u);
+        }
     }
     __syncthreads();
-    if (threadIdx.x <= mask) hist[(size_t)threadIdx.x * (size_t)ntiles + blockIdx.x] = h[threadIdx.x];
+    if (threadIdx.x <= mask) hist[(size_t)threadIdx.x * (size_t)ntiles + blockIdx.x] = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
 }
 
 // exclusive scan of 256 values held one per thread (the calling workgroup has 256 threads); returns the exclusive prefix,
@@ -93,14 +113,20 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_scatter(const K *__restrict__
                                                           uint32_t *__restrict__ vals_out)
 {
     constexpr int TILE = SORT_BLK * ITEMS;
-    __shared__ K skeys[TILE];
-    __shared__ uint32_t svals[TILE];
+    __shared__ K skeys[TILE];                  // the keys in digit order; then, in the same storage, the values (more workgroups per CU than with both at once)
     __shared__ uint32_t wrun[SORT_WAVES][256]; // first the wave's digit counts, then its running positions
     __shared__ uint32_t goff[256];             // global position of local position 0 of each digit's run (may wrap: uint arithmetic)
     __shared__ uint32_t sh[SORT_WAVES];
     const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tile = (int)blockIdx.x;
+    // XCD-aware placement: workgroups are dealt to the 8 XCDs in turn, so the ones with equal blockIdx % 8 share an L2.  Each
+    // of those groups takes a CONTIGUOUS eighth of the tiles: the runs of one digit written by neighbouring tiles are
+    // neighbours in memory, and the partial cache lines at their seams then meet in one L2 before they go out.
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, x8 = (int)blockIdx.x & 7;
+    const int tile = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + ((int)blockIdx.x >> 3);
     const int64_t base = (int64_t)tile * TILE + (int64_t)w * (TILE / SORT_WAVES);
+    // (asked for now, used after the counting: global start of digit d = totals of the smaller digits + this digit's prefix over the earlier tiles)
+    const uint32_t tot = ((uint32_t)tid <= mask) ? totals[tid] : 0u;
+    const uint32_t before = ((uint32_t)tid <= mask) ? hist[(size_t)tid * (size_t)ntiles + tile] : 0u;
 #pragma unroll
     for (int k = 0; k < SORT_WAVES; ++k) wrun[k][tid] = 0u;
     __syncthreads();
@@ -121,16 +147,15 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_scatter(const K *__restrict__
 #pragma unroll
         for (int k = 0; k < SORT_WAVES; ++k) { c[k] = wrun[k][tid]; tile_count += c[k]; }
         const uint32_t dstart = block_excl_scan_256(tile_count, sh, nullptr);
-        // global start of digit d = sum of the totals of the smaller digits + this digit's prefix over the earlier tiles
-        const uint32_t tot = ((uint32_t)tid <= mask) ? totals[tid] : 0u;
         const uint32_t gbase = block_excl_scan_256(tot, sh, nullptr);
         uint32_t run = dstart;
 #pragma unroll
         for (int k = 0; k < SORT_WAVES; ++k) { wrun[k][tid] = run; run += c[k]; }
-        goff[tid] = ((uint32_t)tid <= mask) ? gbase + hist[(size_t)tid * (size_t)ntiles + tile] - dstart : 0u;
+        goff[tid] = ((uint32_t)tid <= mask) ? gbase + before - dstart : 0u;
     }
     __syncthreads();
     // stable ranking, wave-private
+    uint32_t pos[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = base + r * 64 + lane;
@@ -142,26 +167,39 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_scatter(const K *__restrict__
             peers &= ((d >> b) & 1u) ? bal : ~bal;
         }
         const unsigned long long below = peers & ((1ull << lane) - 1ull);
-        uint32_t pos = 0;
-        if (in) pos = wrun[w][d] + (uint32_t)__popcll(below);
+        pos[r] = 0u;
+        if (in) pos[r] = wrun[w][d] + (uint32_t)__popcll(below);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (in && below == 0ull) wrun[w][d] += (uint32_t)__popcll(peers);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (in) { skeys[pos] = key[r]; svals[pos] = val[r]; }
+        if (in) skeys[pos[r]] = key[r];
     }
     __syncthreads();
     const int64_t tile_n = min((int64_t)TILE, n - (int64_t)tile * TILE);
+    uint32_t o[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int j = it * SORT_BLK + tid;
+        o[it] = 0u;
         if (j < tile_n) {
             const K k = skeys[j];
-            const uint32_t o = goff[(uint32_t)(k >> shift) & mask] + (uint32_t)j;
-            keys_out[o] = k;
-            if (vals_out) vals_out[o] = svals[j];
+            o[it] = goff[(uint32_t)(k >> shift) & mask] + (uint32_t)j;
+            keys_out[o[it]] = k;
         }
+    }
+    if (!vals_out) return;
+    __syncthreads();
+    uint32_t *svals = reinterpret_cast<uint32_t *>(skeys);
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r)
+        if (base + r * 64 + lane < n) svals[pos[r]] = val[r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int j = it * SORT_BLK + tid;
+        if (j < tile_n) vals_out[o[it]] = svals[j];
     }
 }
 

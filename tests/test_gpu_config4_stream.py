@@ -80,11 +80,15 @@ def test_1000_scan_stream_with_imu_ekf_and_map_growth(api, ctx, orc, synth):
                 exp, _, _, st = orc.voxel_pcl(cat, 0.1)
                 assert st == 0
                 assert np.array_equal(flow.map_full_.download(), exp), "grown map differs from the oracle at growth step %d" % g0
+                # the index carried over this step (sf_map_patch) is the index a build of the grown map gives, bit for bit
+                cell = flow.map_index_.cell_size()[0]
+                got, want = flow.map_index_.index(), api.Map(ctx, flow.map_full_, cell).index()
+                assert all(np.array_equal(got[key].view(np.uint32), want[key].view(np.uint32)) for key in ("pts4", "cell_start", "org")), "index differs from a rebuild at growth step %d" % g0
                 checked += 1
                 snap.clear()
     errs, rot_errs = np.array(errs), np.array(rot_errs)
-    print("config 4: median / p99 / max translation error %.3f / %.3f / %.3f m, rotation %.4f rad, %d growth steps (%d checked), map %d -> %d points"
-          % (np.median(errs), np.quantile(errs, 0.99), errs.max(), np.median(rot_errs), flow.growths_, checked, n_map[0], n_map[-1]))
+    print("config 4: median / p99 / max translation error %.3f / %.3f / %.3f m, rotation %.4f rad, %d growth steps (%d checked, %d merged, %d with the index patched), map %d -> %d points"
+          % (np.median(errs), np.quantile(errs, 0.99), errs.max(), np.median(rot_errs), flow.growths_, checked, flow.merges_, flow.patches_, n_map[0], n_map[-1]))
     assert flow.growths_ == (N_SCANS - 1) // 10 and checked == len(check_at)
     api.voxel_merge_min_points(prev_min)
     assert flow.merges_ >= flow.growths_ - 2                             # the growth steps took the merge path (sf_cloud_voxel_merge), bit-equal to the oracle above

@@ -87,7 +87,9 @@ def main():
                       "scans_per_s": float(1.0 / np.mean(times)), "translation_err_m_median": float(np.median(errs)),
                       "translation_err_m_max": float(np.max(errs)), "reference_budget_ms": 100.0,
                       "orchestration": type(flow).__name__, "graph_captures_and_launches": list(flow.icp_.graph_counts()),
-                      "single_launch_alignments": flow.icp_.fused_count()}))
+                      "single_launch_alignments": flow.icp_.fused_count(),
+                      **({"growth_steps": flow.growths_, "growth_steps_merged": flow.merges_, "growth_steps_index_patched": flow.patches_, "map_points_end": len(flow.map_full_)}
+                         if hasattr(flow, "patches_") else {})}))
 
 
 if __name__ == "__main__":
