@@ -164,8 +164,14 @@ int sf_map_cell_size(sf_map *m, float *cell, int32_t dims[3]);
  * sf_cloud_voxel_merge(cloud, ...) wrote, when `m` indexes `cloud` as it was before that merge and nothing has touched
  * the cloud since: the entries that stay keep their order (one streaming pass), only the new centroids are sorted.
  * Takes the build itself whenever that does not hold (the merge took its full path, the cloud changed in between, the
- * smallest coordinate of the map moved, 64-bit cell ids); *patched (may be NULL) says which way it went.  Normals and
- * the window are dropped as sf_map_build drops them; re-attach the map to its sf_icp (sf_icp_set_target). */
+ * smallest coordinate of the map moved, 64-bit cell ids); *patched (may be NULL) says which way it went: 1 = merged,
+ * SF_PATCH_* (<= 0) = built, and why.  Normals and the window are dropped as sf_map_build drops them; re-attach the map
+ * to its sf_icp (sf_icp_set_target). */
+#define SF_PATCH_NO_MERGE        0   /* no usable record: the merge took its full path, the cloud changed since, another cloud's index */
+#define SF_PATCH_BOUND_REPLACED (-1) /* (not returned any more: a replaced bound costs one reduction over the cloud, then the patch goes on) */
+#define SF_PATCH_ORIGIN_MOVED   (-2) /* a new centroid lies below the grid origin: every cell changes */
+#define SF_PATCH_LIMITS         (-3) /* 2^28 points / 2^32 cells / table memory */
+#define SF_PATCH_CLAMPED_POINT  (-4) /* a point the old grid had clamped to its upper face now lies in a cell of its own */
 int sf_map_patch(sf_map *m, sf_cloud *cloud, int *patched);
 /* the index as it lies in HBM, for parity tests: points indexed, cells, grid origin, 1 / cell, the pruning slack;
  * pts4 = float[n][4] (x, y, z, bitcast point id) in cell order, cell_start = uint32[n_cells + 1] (either may be NULL) */

@@ -360,7 +360,8 @@ class Map:
         """sf_map_patch: the index after the last `cloud.voxel_merge(...)`, merged from the old one when it can be; -> True if it was."""
         done = C.c_int(0)
         _check(self.lib.sf_map_patch(self.h, cloud.h, C.byref(done)))
-        return bool(done.value)
+        self.last_patch = done.value                          # 1 merged, SF_PATCH_* (<= 0): built, and why (include/slamfusion.h)
+        return done.value > 0
 
     def index(self):
         """The index as it lies on the device (parity tests): dict(pts4 [n, 4] float32 with the point id bit-cast into column 3,

@@ -282,10 +282,11 @@ struct PatchGeom { float org[3]; float inv_h; int dim[3]; int old_dim[3]; };
 
 __device__ __forceinline__ uint32_t patch_key(const PatchGeom &g, float x, float y, float z, bool *moved)
 {
-    const int cx = (int)fminf(fmaxf(floorf((x - g.org[0]) * g.inv_h), 0.0f), (float)(g.dim[0] - 1));
-    const int cy = (int)fminf(fmaxf(floorf((y - g.org[1]) * g.inv_h), 0.0f), (float)(g.dim[1] - 1));
-    const int cz = (int)fminf(fmaxf(floorf((z - g.org[2]) * g.inv_h), 0.0f), (float)(g.dim[2] - 1));
-    if (moved) *moved = cx > g.old_dim[0] - 1 || cy > g.old_dim[1] - 1 || cz > g.old_dim[2] - 1; // the old grid clamped it into another cell
+    // the coordinates before the clamp to the upper face, then under the new and under the old grid
+    const int rx = (int)fminf(fmaxf(floorf((x - g.org[0]) * g.inv_h), 0.0f), 2.0e9f), ry = (int)fminf(fmaxf(floorf((y - g.org[1]) * g.inv_h), 0.0f), 2.0e9f),
+              rz = (int)fminf(fmaxf(floorf((z - g.org[2]) * g.inv_h), 0.0f), 2.0e9f);
+    const int cx = min(rx, g.dim[0] - 1), cy = min(ry, g.dim[1] - 1), cz = min(rz, g.dim[2] - 1);
+    if (moved) *moved = cx != min(rx, g.old_dim[0] - 1) || cy != min(ry, g.old_dim[1] - 1) || cz != min(rz, g.old_dim[2] - 1); // one of the grids clamps it into another cell
     return ((uint32_t)cz * (uint32_t)g.dim[1] + (uint32_t)cy) * (uint32_t)g.dim[0] + (uint32_t)cx;
 }
 
@@ -434,17 +435,36 @@ extern "C" int sf_map_patch(sf_map *m, sf_cloud *cloud, int *patched)
     const SfGrid old = m->grid;
     const uint64_t old_cells = (uint64_t)old.dim[0] * (uint64_t)old.dim[1] * (uint64_t)old.dim[2];
     const int64_t n_old = rec.n_old, ng = rec.n_groups, n_out = cloud->n;
-    if (!rec.valid || rec.epoch != ctx->merge_epoch || rec.stamp_after != cloud->stamp || rec.stamp_before != m->src_stamp || n_old != m->n || old.n != m->n || ng <= 0 ||
-        n_out != n_old + rec.n_fresh || n_out >= (int64_t)(1 << 28) || old_cells >= 0xffffffffull)
+    auto rebuild = [&](int why) -> int { // *patched: 0 / negative = the build ran, and why
+        if (patched) *patched = why;
         return sf_map_build(m, cloud, cell);
+    };
+    if (!rec.valid || rec.epoch != ctx->merge_epoch || rec.stamp_after != cloud->stamp || rec.stamp_before != m->src_stamp || n_old != m->n || old.n != m->n || ng <= 0 ||
+        n_out != n_old + rec.n_fresh)
+        return rebuild(SF_PATCH_NO_MERGE);
+    if (n_out >= (int64_t)(1 << 28) || old_cells >= 0xffffffffull) return rebuild(SF_PATCH_LIMITS);
 
     // 1. do the bounds of the map survive?  (the merge looked: sf_voxel.hip, k_merge_extremes)
-    if (rec.touched_extreme) return sf_map_build(m, cloud, cell);
     float new_mx[3];
-    for (int d = 0; d < 3; ++d) {
-        if (rec.old_mn[d] != old.org[d] || rec.old_mx[d] != m->src_mx[d]) return sf_map_build(m, cloud, cell); // (not the bounds this index was built on)
-        if (!(rec.cen_mn[d] > old.org[d])) return sf_map_build(m, cloud, cell); // the origin would move: every cell changes
-        new_mx[d] = std::max(m->src_mx[d], rec.cen_mx[d]);
+    for (int d = 0; d < 3; ++d)
+        if (rec.old_mn[d] != old.org[d] || rec.old_mx[d] != m->src_mx[d]) return rebuild(SF_PATCH_NO_MERGE); // (not the bounds this index was built on)
+    if (rec.touched_extreme) {
+        // a point that held a bound was replaced: one reduction over the merged cloud says what the bounds are now (a tenth
+        // of a build); the patch goes on if the smallest coordinates are what they were
+        sf::MinMaxHost mm;
+        SF_TRY(sf::cloud_minmax(ctx, cloud->xyz.as<float>(), n_out, &mm));
+        if (mm.n_finite != n_out) return rebuild(SF_PATCH_BOUND_REPLACED);
+        for (int d = 0; d < 3; ++d) { cloud->bounds_mn[d] = mm.mn[d]; cloud->bounds_mx[d] = mm.mx[d]; }
+        cloud->bounds_stamp = cloud->stamp; // (the next merge need not look again)
+        for (int d = 0; d < 3; ++d) {
+            if (mm.mn[d] != old.org[d]) return rebuild(SF_PATCH_ORIGIN_MOVED);
+            new_mx[d] = mm.mx[d];
+        }
+    } else {
+        for (int d = 0; d < 3; ++d) {
+            if (!(rec.cen_mn[d] > old.org[d])) return rebuild(SF_PATCH_ORIGIN_MOVED); // every cell changes
+            new_mx[d] = std::max(m->src_mx[d], rec.cen_mx[d]);
+        }
     }
 
     // 2. the geometry a build of the merged cloud would choose (sf_map_build, step 2, explicit cell)
@@ -458,13 +478,13 @@ extern "C" int sf_map_patch(sf_map *m, sf_cloud *cloud, int *patched)
     double cells = 1;
     for (int d = 0; d < 3; ++d) {
         const double c = std::floor(((double)new_mx[d] - (double)old.org[d]) / h) + 1;
-        if (c > 2.0e9) return sf_map_build(m, cloud, cell);
+        if (c > 2.0e9) return rebuild(SF_PATCH_LIMITS);
         g.org[d] = pg.org[d] = old.org[d];
         g.dim[d] = pg.dim[d] = (int)c;
         pg.old_dim[d] = old.dim[d];
         cells *= c;
     }
-    if (cells > max_cells || cells >= 4294967295.0) return sf_map_build(m, cloud, cell);
+    if (cells > max_cells || cells >= 4294967295.0) return rebuild(SF_PATCH_LIMITS);
     g.inv_h = pg.inv_h = old.inv_h;
     g.ncell = (uint64_t)g.dim[0] * (uint64_t)g.dim[1] * (uint64_t)g.dim[2];
     const bool by_scan = g.ncell > (1ull << 28);
@@ -509,7 +529,7 @@ extern "C" int sf_map_patch(sf_map *m, sf_cloud *cloud, int *patched)
     SF_HIP(hipGetLastError());
     SF_HIP(hipStreamSynchronize(st));
     m->pts4.swap(m->pts4_alt);
-    if (h_ext->moved) return sf_map_build(m, cloud, cell); // a point that the old grid had clamped to its upper face: its cell, and the order, changed
+    if (h_ext->moved) return rebuild(SF_PATCH_CLAMPED_POINT); // a point that the old grid had clamped to its upper face: its cell, and the order, changed
 
     m->n = n_out;
     m->has_normals = false;

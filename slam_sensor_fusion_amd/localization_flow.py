@@ -321,6 +321,7 @@ class ImuEkfMappingFlow(EkfLocalizationFlow):
         self.growths_ = 0
         self.merges_ = 0                                      # growth steps that took the merge path of sf_cloud_voxel_merge
         self.patches_ = 0                                     # ... and whose index was merged from the old one (sf_map_patch)
+        self.patch_codes_ = {}                                # sf_map_patch's answer (1 / SF_PATCH_*) -> growth steps
         self.on_grow = None                                   # test hook: on_grow(flow) just before a growth step
 
     def pose_prior(self, gps, odom, odom_T_sensor_current):
@@ -370,6 +371,7 @@ class ImuEkfMappingFlow(EkfLocalizationFlow):
         if self.index_stride_ == 1:                           # the index is built straight from the voxel-filtered map (it copies what it needs)
             if self.index_cloud_ is self.map_full_:           # ... and carried over the growth step when it indexed this very cloud before the merge
                 self.patches_ += int(self.map_index_.patch(self.map_full_))
+                self.patch_codes_[self.map_index_.last_patch] = self.patch_codes_.get(self.map_index_.last_patch, 0) + 1
             else:
                 self.index_cloud_ = self.map_full_
                 self.map_index_.build(self.index_cloud_, 0.0)

@@ -87,8 +87,8 @@ def test_1000_scan_stream_with_imu_ekf_and_map_growth(api, ctx, orc, synth):
                 checked += 1
                 snap.clear()
     errs, rot_errs = np.array(errs), np.array(rot_errs)
-    print("config 4: median / p99 / max translation error %.3f / %.3f / %.3f m, rotation %.4f rad, %d growth steps (%d checked, %d merged, %d with the index patched), map %d -> %d points"
-          % (np.median(errs), np.quantile(errs, 0.99), errs.max(), np.median(rot_errs), flow.growths_, checked, flow.merges_, flow.patches_, n_map[0], n_map[-1]))
+    print("config 4: median / p99 / max translation error %.3f / %.3f / %.3f m, rotation %.4f rad, %d growth steps (%d checked, %d merged, %d with the index patched: %s), map %d -> %d points"
+          % (np.median(errs), np.quantile(errs, 0.99), errs.max(), np.median(rot_errs), flow.growths_, checked, flow.merges_, flow.patches_, flow.patch_codes_, n_map[0], n_map[-1]))
     assert flow.growths_ == (N_SCANS - 1) // 10 and checked == len(check_at)
     api.voxel_merge_min_points(prev_min)
     assert flow.merges_ >= flow.growths_ - 2                             # the growth steps took the merge path (sf_cloud_voxel_merge), bit-equal to the oracle above

@@ -127,8 +127,8 @@ def _same_index(a, b):
 def test_index_patch_equals_rebuild(api, ctx, synth):
     """sf_map_patch == sf_map_build of the merged cloud with the same cell (points in cell order with their ids, cell table,
     geometry: bit for bit) over growth steps that touch voxels, open new ones inside and beyond the map's
-    upper faces (the grid gets more cells per row: every cell id changes, the order does not), and the cases that must
-    take the build: the smallest coordinate moves, the cloud was changed between merge and patch, the merge took its full
+    upper faces (the grid gets more cells per row: every cell id changes, the order does not), that replace a point which
+    held one of the map's bounds, and the cases that must take the build: the smallest coordinate moves, the cloud was changed between merge and patch, the merge took its full
     path, the index is of another cloud.  setTargetPointCloud after `*map_cloud += *cloud` + VoxelGrid:
     icp_point_to_point.cpp:49-55, global_map_frames_manager.cpp:131,142-146."""
     rng = np.random.default_rng(9)
@@ -150,10 +150,15 @@ def test_index_patch_equals_rebuild(api, ctx, synth):
             def top():                                                # the point that holds the largest y right now
                 pts = dev.download()
                 return pts[np.argmax(pts[:, 1])]
+
+            def bottom():                                             # ... the smallest x
+                pts = dev.download()
+                return pts[np.argmin(pts[:, 0])]
             steps = [("touch + fill", near(30_000), True),
                      ("beyond +x / +y / +z", np.concatenate([near(5_000), (rng.uniform(0, 1, (20_000, 3)) * (hi - lo + [3.0, 2.0, 1.0]) + lo + 0.01).astype(np.float32)]), True),
                      ("duplicates", np.repeat(near(200), 30, axis=0), True),
-                     ("an extreme point is replaced", lambda: np.concatenate([near(1_000), (top() - np.float32(0.001))[None]]), False),
+                     ("the point that holds the largest y is replaced", lambda: np.concatenate([near(1_000), (top() - np.float32(0.001))[None]]), True),   # (one reduction for the new bounds, then patched)
+                     ("the point that holds the smallest x is replaced", lambda: np.concatenate([near(1_000), (bottom() + np.float32(0.001))[None]]), False),  # (the origin moves with its centroid)
                      ("below the origin", np.concatenate([near(1_000), (lo - [0.5, 0.0, 0.0]).astype(np.float32)[None]]), False)]
             for name, add, expect in steps:
                 add = add() if callable(add) else add
