@@ -173,7 +173,12 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
 
     // 1. bounds of the finite points
     sf::MinMaxHost mm;
-    SF_TRY(sf::cloud_minmax(ctx, xyz, n, &mm));
+    if (n > 0 && cloud->stamp != 0 && cloud->bounds_stamp == cloud->stamp) { // left behind by a voxel merge: all points finite, nothing has changed since
+        for (int d = 0; d < 3; ++d) { mm.mn[d] = cloud->bounds_mn[d]; mm.mx[d] = cloud->bounds_mx[d]; }
+        mm.n_finite = n;
+    } else {
+        SF_TRY(sf::cloud_minmax(ctx, xyz, n, &mm));
+    }
     const int64_t n_valid = mm.n_finite;
 
     // 2. geometry: automatic cell ~ 1.5 points per cell, clamped; grow until it fits u32

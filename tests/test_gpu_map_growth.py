@@ -169,6 +169,9 @@ def test_index_patch_equals_rebuild(api, ctx, synth):
                 ref = api.Map(ctx, dev, h)
                 assert _same_index(mp.index(), ref.index()) == "", (name, cell, _same_index(mp.index(), ref.index()))
                 assert mp.cell_size() == ref.cell_size() and len(mp) == len(ref) == len(dev)
+                pts = dev.download()                                  # (the bounds the merge carries over are the bounds of the points)
+                assert np.array_equal(ref.index()["org"], pts.min(0))
+                assert ref.cell_size()[1] == tuple(int(np.floor((float(pts[:, d].max()) - float(pts[:, d].min())) / float(h))) + 1 for d in range(3))
                 if name.startswith("beyond"):
                     assert mp.cell_size()[1] != dims0                 # more cells per row: the patch renumbered them
             # the patched index answers like the rebuilt one
