@@ -784,7 +784,7 @@ def main():
             "map_points_start_end": [int(n0), int(len(flow.map_full_))],
             "drift_translation_m": {"median": float(np.median(errs_)), "last_100_median": float(np.median(errs_[-100:])), "max": float(np.max(errs_))},
             "what": "sequential 1000-scan stream: 15-state EKF with 100 Hz IMU pre-integration as the prior, O3D_P2P registration per scan (single launch), registered scans "
-                    "appended on the device, voxel grid 0.1 m merged and the index carried over (sf_map_patch) every 10 scans; host clock around every callback; reference budget 100 ms per scan"}
+                    "appended on the device, voxel grid 0.1 m + grid index every 10 scans (re-filtered and rebuilt on the hand-written radix sort at this map size; from 4 M map points on the filter is a merge and the index is carried over, sf_cloud_voxel_merge / sf_map_patch: tools/growth_bench.py); host clock around every callback; reference budget 100 ms per scan"}
         flow = None
         sctx.synchronize()
 
