@@ -237,3 +237,52 @@ def test_index_patch_registration_identical(api, ctx, synth):
         assert np.array_equal(na[0], nb[0]) and np.array_equal(na[1], nb[1])
     finally:
         api.voxel_merge_min_points(prev)
+
+
+def test_index_patch_edge_cases(api, ctx, synth):
+    """sf_map_patch where one side of the merge is empty or odd: every pending point re-observes an existing voxel (no new
+    voxel: ids do not shift), none does (only new voxels), non-finite pending points, one pending point; and a sparse map whose
+    cell table is built by scan (more than 2^28 cells).  Always bit-identical to sf_map_build of the merged cloud."""
+    rng = np.random.default_rng(21)
+    prev = api.voxel_merge_min_points(0)
+    try:
+        base = synth.make_map(200_000)
+        inner = base[(np.abs(base[:, 0]) < 5.0) & (np.abs(base[:, 1]) < 5.0) & (np.abs(base[:, 2]) < 4.0)]
+        dev = api.Cloud(ctx, inner)
+        dev.voxel_downsample(0.1, "pcl")
+        mp = api.Map(ctx, dev, 0.25)
+        pts = dev.download()
+        core = pts[(np.abs(pts[:, 0]) < 4.5) & (np.abs(pts[:, 1]) < 4.5) & (np.abs(pts[:, 2]) < 3.5)]
+        free = (np.floor(rng.uniform(-4, 4, (3000, 3)) * 10) / 10 + 0.05).astype(np.float32)          # voxel centres ...
+        occupied = {tuple(v) for v in np.floor(pts / 0.1).astype(np.int64)}
+        free = np.array([p for p in free if tuple(np.floor(p / 0.1).astype(np.int64)) not in occupied], np.float32)   # ... of voxels the map does not have
+        nan_mix = np.concatenate([core[:500] + np.float32(0.002), np.full((3, 3), np.nan, np.float32), free[:50] + np.float32(0.01)])
+        steps = [("only re-observed voxels", core[rng.choice(len(core), 5_000, replace=False)].copy(), 0),
+                 ("only new voxels", free[: len(free) // 2], None),
+                 ("non-finite pending points", nan_mix, None),
+                 ("one pending point", core[7:8] + np.float32(0.001), 0)]
+        for name, add, grew in steps:
+            n0 = len(dev)
+            st, merged = dev.voxel_merge(api.Cloud(ctx, add), 0.1)
+            assert st == 0 and merged, name
+            if grew is not None:
+                assert len(dev) - n0 == grew, name
+            assert mp.patch(dev), (name, mp.last_patch)
+            assert _same_index(mp.index(), api.Map(ctx, dev, 0.25).index()) == "", name
+        # sparse map, 300 m x 300 m x 20 m (PCL's int32 voxel index still holds) at a 0.15 m cell: 5.4e8 cells, the table built by scan
+        corners = np.array([[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5]]) * np.array([285.0, 285.0, 8.0])
+        sparse = np.concatenate([c + synth.make_map(40_000, seed=60 + k)[:20_000] % 10.0 for k, c in enumerate(corners)]).astype(np.float32)
+        sparse = np.concatenate([sparse, np.array([[-1, -1, -1], [299, 299, 19]], np.float32)])   # pin the bounds away from the clusters
+        big = api.Cloud(ctx, sparse)
+        assert big.voxel_downsample(0.1, "pcl") == 0
+        mb = api.Map(ctx, big, 0.15)
+        assert np.prod(np.array(mb.cell_size()[1], dtype=np.float64)) > 2.0 ** 28
+        add = (corners[2] + rng.uniform(0, 12, (8_000, 3))).astype(np.float32)
+        st, merged = big.voxel_merge(api.Cloud(ctx, add), 0.1)
+        assert st == 0 and merged
+        assert mb.patch(big), mb.last_patch
+        ref = api.Map(ctx, big, 0.15)
+        a, b = mb.index(), ref.index()
+        assert _same_index(a, b) == ""
+    finally:
+        api.voxel_merge_min_points(prev)
