@@ -300,10 +300,12 @@ int sf_icp_set_query_order(sf_icp *icp, int order);
  * search is skipped.  Results are bit-identical with the switch on or off (tested); it only
  * changes how much of the "nearest neighbour every iteration" work has to be redone. */
 int sf_icp_set_nn_reuse(sf_icp *icp, int on);
-/* Scans above `points` points (default and maximum 131 072: what the single-launch kernels can take) are registered through the
- * launch list with two queries per lane -- the form the frozen pairs need.  A full 64-ring scan (<= 130 048 returns) stays below
- * the default and never freezes; a caller that registers such scans in batches lowers the limit (e.g. 65 536) before setting the
- * source.  The limit is part of the summation order: results on either side of it agree to float64 rounding, not bitwise. */
+/* Scans above `points` points (at most 131 072: what the single-launch kernels can take) are registered through the launch list with
+ * two queries per lane -- the form the frozen pairs need.  Without a call the rule is: above 131 072 points always; above 65 536 when
+ * the batch has more rows than any single-launch kernel keeps resident (so no alignment of that shape could run as one launch:
+ * nothing to stay bit-compatible with) -- a full 64-ring scan (<= 130 048 returns) registered in a batch is wide and may freeze,
+ * registered alone it is not.  A call makes `points` the whole rule.  The limit is part of the summation order: results on either
+ * side of it agree to float64 rounding, not bitwise. */
 int sf_icp_set_wide_scan_points(sf_icp *icp, int64_t points);
 /* Consecutive sf_icp_align_batch_async calls on unchanged inputs (source, initial poses, target) overlap: a launch list
  * enqueued while an earlier alignment of this object has not been fetched yet runs on an internal stream with its own copy of

@@ -487,6 +487,7 @@ __global__ void k_state_init(IcpState *__restrict__ st, const double *__restrict
 #define SF_WIDE_QPL 2
 #endif
 constexpr int64_t WIDE_SCAN_POINTS = 131072;
+constexpr int64_t WIDE_AUTO_POINTS = 65536; // see sf_icp::wide_auto
 constexpr int VERIFY_FROM_SEARCH = 4; // wide scans: from the fifth launch of an alignment on a wave first tries to verify all its queries at once
 #ifndef NN_RED_WAVES
 #define NN_RED_WAVES 4
@@ -2893,6 +2894,7 @@ struct sf_icp {
     int nblocks_nn = 0;      // k_nn_red workgroups per scan = slab rows (256 * qpl queries each)
     int qpl = 1;             // queries per lane of k_nn_red: 1 up to wide_from points per scan, SF_WIDE_QPL beyond (part of the summation order)
     int64_t wide_from = WIDE_SCAN_POINTS; // sf_icp_set_wide_scan_points: scans above this many points take two queries per lane (and may freeze)
+    bool wide_auto = true;   // no explicit limit: scans above WIDE_AUTO_POINTS are wide too when the batch is beyond every single-launch kernel (set_source_common)
     std::vector<IcpState> h_state;
     // sharding
     bool shard = false;
@@ -2998,6 +3000,8 @@ const float *src(sf_icp *icp, int axis)
     if (icp->shard) return soa(icp->Xq, icp->own_total, axis); // compact, cell-ordered owned queries (shard_build)
     return soa(icp->ordered ? icp->Xq : icp->X0, icp->plane, axis);
 }
+
+int fused_capacity(sf_icp *icp, int mode); // (workgroups the single-launch kernels keep resident; defined with them)
 
 // AUTO orders when there is enough work for the order to pay for the sort.  Measured, 200 k-point
 // scans, 20 iterations: 1 scan in flight +1.5 % (break-even), 2: +8 %, 4: +32 %, 32: +65 %
@@ -3187,7 +3191,15 @@ int icp_alloc(sf_icp *icp, int64_t n, int batch)
     // device memory), so the launch geometry -- and with it a captured graph -- is shared by scans of similar size
     icp->n_cap = batch == 1 ? sf::div_up(std::max<int64_t>(n, 1), 4096) * 4096 : n;
     icp->nblocks = (int)std::max<int64_t>(1, sf::div_up(icp->n_cap, BLK));
-    icp->qpl = n > icp->wide_from ? SF_WIDE_QPL : 1;
+    // Two queries per lane are part of the summation order, so the choice must not depend on which path runs an alignment: above
+    // wide_from always; between WIDE_AUTO_POINTS and wide_from when no single-launch kernel could take the batch anyway (more
+    // rows than any of them keeps resident) -- a 64-ring sensor's 130 k points in a batch then run wide and may freeze.
+    bool wide = n > icp->wide_from;
+    if (!wide && icp->wide_auto && n > WIDE_AUTO_POINTS) {
+        const int64_t cap = std::max(fused_capacity(icp, SF_ICP_O3D_P2P), fused_capacity(icp, SF_ICP_P2PLANE));
+        wide = sf::div_up(n, BLK) * (int64_t)batch > cap;
+    }
+    icp->qpl = wide ? SF_WIDE_QPL : 1;
     icp->nblocks_nn = (int)std::max<int64_t>(1, sf::div_up(n, BLK * icp->qpl));
     SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)REC_STRIDE * (size_t)icp->nblocks * (size_t)batch));
     SF_TRY(icp->xchg_own.reserve(sizeof(double) * REC_STRIDE * (size_t)batch));
@@ -3917,6 +3929,7 @@ extern "C" int sf_icp_set_wide_scan_points(sf_icp *icp, int64_t points)
 {
     SF_CHECK(icp && points >= 1024 && points <= WIDE_SCAN_POINTS, SF_ERR_INVALID, "the limit must lie in [1 024, 131 072] (what the single-launch kernels can take)");
     icp->wide_from = points; // takes effect with the next source
+    icp->wide_auto = false;  // an explicit limit is the whole rule
     return SF_OK;
 }
 

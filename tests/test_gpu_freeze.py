@@ -198,29 +198,39 @@ def test_the_schedule_learnt_from_the_last_alignment_changes_no_result(api, ctx,
 
 
 def test_a_lower_wide_scan_limit_lets_smaller_scans_freeze(api, ctx, synth, world):
-    """A full 64-ring scan has at most 130 048 returns: below the 131 072-point limit of the single-launch kernels it keeps one
-    query per lane and never freezes.  sf_icp_set_wide_scan_points moves the limit for callers that register such scans in
-    batches: the same pairs, poses equal to float64 rounding, and the scans freeze."""
+    """A full 64-ring scan has at most 130 048 returns: below the 131 072 points the single-launch kernels take.  With an explicit
+    limit of 131 072 such scans keep one query per lane and never freeze; with a lower limit (sf_icp_set_wide_scan_points) they
+    run wide and freeze: the same pairs, poses equal to float64 rounding.  Without a call the library decides: wide when the
+    batch has more rows than any single-launch kernel keeps resident (three scans of 100 000 points: 1 173 rows), not wide for
+    one scan alone (391 rows: the single launch takes it)."""
     scans = world["scans"][:, :100_000].copy()
 
-    def go(limit, freeze):
+    def go(limit, freeze, batch=3):
         icp = api.Icp(ctx, 0.5, 20, 0.05, 1e-5)
         icp.set_target(world["mp"])
         icp.set_query_order("cell")
         icp.set_freeze(freeze)
         if limit:
             icp.set_wide_scan_points(limit)
-        icp.set_source_batch(scans)
-        icp.set_initial_batch(world["inits"])
+        icp.set_source_batch(scans[:batch])
+        icp.set_initial_batch(world["inits"][:batch])
         r = icp.align_batch("p2plane")
         s = icp.freeze_stats()
+        fused = icp.fused_count()
         icp.close()
-        return r, s
-    plain, s0 = go(None, True)
-    assert s0["froze"] == 0                                   # 100 000 points: one query per lane, nothing to freeze
-    wide, s1 = go(65536, True)
+        return r, s, fused
+    plain, s0, _ = go(131072, True)
+    assert s0["froze"] == 0                                   # one query per lane, nothing to freeze
+    wide, s1, _ = go(65536, True)
     assert s1["froze"] >= 3 and s1["frozen_at_end"] == 3
     same_result(wide, plain, tol=1e-10)
+    auto, s2, f2 = go(None, True)                             # the library's rule: this batch is beyond every single launch -> wide
+    assert s2["froze"] >= 3 and f2 == 0
+    bitwise(auto, wide)
+    one_auto, s3, f3 = go(None, True, batch=1)                # one scan alone: a single launch, one query per lane
+    one_plain, _, f4 = go(131072, True, batch=1)
+    assert s3["froze"] == 0 and f3 == f4
+    bitwise(one_auto, one_plain)
     with pytest.raises(api.SlamFusionError):
         api.Icp(ctx, 0.5, 20, 0.05, 1e-5).set_wide_scan_points(200_000)
 

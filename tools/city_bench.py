@@ -8,8 +8,8 @@ localization_node.cpp:292-305,329-337).
 
 One JSON line per (rings, prior error) case: scans/s with the library's defaults, with the frozen pairs off, with the neighbour
 reuse off; per-launch times, the share of queries that search per launch, and sf_icp_freeze_stats (froze / thawed / voided /
-active share).  Frozen pairs need scans above 131 072 points (include/slamfusion.h): a 64-ring scan (<= 130 048 returns) never
-freezes -- that is a result, and the line says so; `--rings 64 128` adds the 128-ring sensor that does.
+active share).  Frozen pairs need wide scans (include/slamfusion.h, sf_icp_set_wide_scan_points): above 131 072 points, or above
+65 536 in a batch that no single launch could take -- a 64-ring scan (<= 130 048 returns) in a batch of 64 qualifies.
    python tools/city_bench.py [--map-points 10000000] [--batch 64] [--rings 64 128] [--prior 0.06:0.3 0.3:1.5]"""
 import argparse
 import json
@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rings", type=int, nargs="+", default=[64, 128])
     ap.add_argument("--prior", nargs="+", default=["0.06:0.3", "0.3:1.5"], help="1-sigma prior error per axis, metres:degrees")
-    ap.add_argument("--wide-from", type=int, default=131072, help="sf_icp_set_wide_scan_points: 65536 lets a 64-ring scan (127 k points) freeze")
+    ap.add_argument("--wide-from", type=int, default=0, help="sf_icp_set_wide_scan_points (0: the library's own rule -- above 131 072 points, or above 65 536 in a batch no single launch could take)")
     args = ap.parse_args()
     mode = "p2plane"
     ctx = api.Context(0)
@@ -75,7 +75,8 @@ def main():
             icp = api.Icp(ctx, 0.5, args.iters, 0.05, 1e-5)
             icp.set_target(mp)
             icp.use_graph(True)
-            icp.set_wide_scan_points(args.wide_from)
+            if args.wide_from > 0:
+                icp.set_wide_scan_points(args.wide_from)
             icp.set_source_batch(scans)
             icp.set_initial_batch(inits)
             out = {}
@@ -85,8 +86,7 @@ def main():
             out["median_translation_err_m"] = float(np.median([e[0] for e in errs]))
             out["scans_per_s"] = timed(icp, ctx, mode, args.steps, args.batch)
             fs = icp.freeze_stats()
-            out["freeze_stats"] = dict(fs, active_share=fs["active_queries"] / float(n * args.batch), scans=args.batch,
-                                       applicable=bool(n > args.wide_from), wide_from=args.wide_from, note="" if n > args.wide_from else "scans of at most 131 072 points never freeze (one query per lane, the single-launch summation order)")
+            out["freeze_stats"] = dict(fs, active_share=fs["active_queries"] / float(n * args.batch), scans=args.batch, wide_from=args.wide_from or "library rule")
             icp.use_graph(False)
             icp.profile_enable(True)
             icp.align_batch_async(mode)
