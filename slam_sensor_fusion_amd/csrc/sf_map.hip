@@ -528,7 +528,8 @@ extern "C" int sf_map_patch(sf_map *m, sf_cloud *cloud, int *patched)
     hipLaunchKernelGGL(k_patch_new, dim3(nblk(ng)), dim3(256), 0, st, pg, old.pts, n_old, bitmap, blk_pre, skey, sval, ng, rec.g_rank, rec.fresh_pos, rec.g_centroid, pts_out, keys_out);
     SF_HIP(hipMemcpyAsync(h_ext, d_ext, sizeof(PatchFlags), hipMemcpyDeviceToHost, st));
 
-    // 5. the cell table from the merged keys
+    // 5. the cell table from the merged keys (from here on the old index is gone: an error leaves the map without one)
+    m->built = false;
     SF_TRY(m->cell_start.reserve(sizeof(uint32_t) * ((size_t)g.ncell + 8)));
     SF_TRY(build_cell_table(m, g, keys_out, n_out, false, by_scan));
     SF_HIP(hipGetLastError());
@@ -537,6 +538,7 @@ extern "C" int sf_map_patch(sf_map *m, sf_cloud *cloud, int *patched)
     if (h_ext->moved) return rebuild(SF_PATCH_CLAMPED_POINT); // a point that the old grid had clamped to its upper face: its cell, and the order, changed
 
     m->n = n_out;
+    m->built = true;
     m->has_normals = false;
     m->window.kind = 0;
     SfGrid &G = m->grid;

@@ -269,6 +269,8 @@ def test_index_patch_edge_cases(api, ctx, synth):
                 assert len(dev) - n0 == grew, name
             assert mp.patch(dev), (name, mp.last_patch)
             assert _same_index(mp.index(), api.Map(ctx, dev, 0.25).index()) == "", name
+        with pytest.raises(api.SlamFusionError):                      # a map without an index has nothing to carry over
+            api.Map(ctx).patch(dev)
         # sparse map, 300 m x 300 m x 20 m (PCL's int32 voxel index still holds) at a 0.15 m cell: 5.4e8 cells, the table built by scan
         corners = np.array([[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5]]) * np.array([285.0, 285.0, 8.0])
         sparse = np.concatenate([c + synth.make_map(40_000, seed=60 + k)[:20_000] % 10.0 for k, c in enumerate(corners)]).astype(np.float32)
