@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--query-order", default="auto", choices=["auto", "as_given", "cell"], help="sf_icp_set_query_order")
     ap.add_argument("--no-nn-reuse", action="store_true", help="sf_icp_set_nn_reuse(0): search every query in every iteration")
     ap.add_argument("--no-freeze", action="store_true", help="sf_icp_set_freeze(0): every launch of an alignment streams every query (rounds 1-3 up to here)")
+    ap.add_argument("--force-freeze", action="store_true", help="sf_icp_set_freeze(2): frozen pairs for batches below the automatic threshold (0.7 M queries) too")
     ap.add_argument("--tile", action="store_true", help="sf_icp_set_tile_search(always): the searching launches served out of LDS tile by tile (sf_tile.hpp; measured "
                                                         "slower than the walk through the global grid index, which stays the default)")
     ap.add_argument("--no-pipeline", action="store_true", help="sf_icp_set_pipeline(0): consecutive steps do not overlap (every alignment on the context's stream)")
@@ -206,7 +207,7 @@ def main():
         icp.use_graph(not args.no_graph)
         icp.set_query_order(args.query_order)
         icp.set_nn_reuse(not args.no_nn_reuse)
-        icp.set_freeze(False if args.no_freeze else "auto")
+        icp.set_freeze(False if args.no_freeze else (True if args.force_freeze else "auto"))
         icp.set_tile_search("always" if args.tile else False)
         icp.set_pipeline(not args.no_pipeline)
         return icp

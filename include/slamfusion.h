@@ -335,7 +335,7 @@ int sf_icp_tile_info(sf_icp *icp, int64_t out[12]);
  * those pairs and the iterations after it evaluate the normal equations from the moments (a polynomial in the pose)
  * instead of streaming the scan; queries too close to a change stay "active" and are evaluated launch by launch.
  * Same pairs, same float64 sums up to summation rounding (~1e-13 of a pose).  on: 0 never, 1 (default) when the batch holds
- * at least 1 M queries -- a frozen launch costs a fixed latency whatever the batch, a small batch is faster
+ * at least 0.7 M queries -- a frozen launch costs a fixed latency whatever the batch, a small batch is faster
  * without --, 2 always.  No reference counterpart (the reference searches every point in every iteration,
  * icp_point_to_point.cpp:64-69). */
 int sf_icp_set_freeze(sf_icp *icp, int on);

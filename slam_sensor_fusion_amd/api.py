@@ -557,7 +557,7 @@ class Icp:
 
     def set_freeze(self, on="auto"):
         """Frozen pairs (sf_icp_set_freeze): P2PLANE launch list of wide scans, see include/slamfusion.h.
-        False / "off", "auto" (default: batches of at least 1 M queries), True / "always"."""
+        False / "off", "auto" (default: batches of at least 0.7 M queries), True / "always"."""
         code = {False: 0, "off": 0, "auto": 1, True: 2, "always": 2}[on]
         _check(self.lib.sf_icp_set_freeze(self.h, C.c_int(code)))
 

@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(RBLK) void k_reduce_solve(IcpState *__restrict__ st
 //   [74,80) x_d x_e   [80,83) x_d   [83,92) p_a x_d (83 + 3 a + d)   [92,95) p_a   95 |p|^2
 constexpr int FZ_NMOM = 96;
 constexpr int FZ_CAP = 128;  // active queries one slab row can list (of its 256 * Q)
-constexpr int64_t FREEZE_AUTO_MIN_QUERIES = 1000000; // sf_icp_set_freeze(1): batches from this many queries on (measured break-even: 0.8 M)
+constexpr int64_t FREEZE_AUTO_MIN_QUERIES = 700000; // sf_icp_set_freeze(1): batches from this many queries on (measured, 200 k-point scans, two lanes: 2 in flight -3 %, 4: +6 %, 8: +1 %; on one lane the break-even was 0.8 M)
 struct FreezeState {
     int mode;         // 0: every query evaluated launch by launch, 1: the next launch is a freeze launch, 2: frozen
     int tries;        // freeze launches that did not hold (a row's list overflowed) + thaws

@@ -33,7 +33,7 @@ def run(api, ctx, world, freeze, graph=False, params=None, scans=None, inits=Non
     icp.use_graph(graph)
     icp.set_query_order("cell")      # (auto orders a batch by cell and a single scan not: another summation order)
     if freeze is not None:
-        icp.set_freeze(freeze)       # True = always; the default ("auto") freezes batches of at least 1 M queries only
+        icp.set_freeze(freeze)       # True = always; the default ("auto") freezes batches of at least 0.7 M queries only
     if params:
         icp.set_freeze_params(**params)
     icp.set_source_batch(world["scans"] if scans is None else scans)
