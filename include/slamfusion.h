@@ -173,6 +173,12 @@ int sf_map_cell_size(sf_map *m, float *cell, int32_t dims[3]);
 #define SF_PATCH_LIMITS         (-3) /* 2^28 points / 2^32 cells / table memory */
 #define SF_PATCH_CLAMPED_POINT  (-4) /* a point the old grid had clamped to its upper face now lies in a cell of its own */
 int sf_map_patch(sf_map *m, sf_cloud *cloud, int *patched);
+/* For a map that is going to grow (sf_map_patch): the grid starts at the multiple of `cells` cells (0 = off, the default: at the
+ * smallest coordinates themselves) below the smallest coordinates, so growth by a few metres in any direction -- below the
+ * origin too -- leaves every point's cell coordinates, and a patch possible; the table gets at most `cells` empty cells per
+ * axis in front of the data.  Takes effect with the next sf_map_build.  Maps that register large BATCHES are better left
+ * without: the scans' ordering keys span the empty margin as well (measured: -4 % at the metric configuration with 64). */
+int sf_map_set_origin_lattice(sf_map *m, int cells);
 /* the index as it lies in HBM, for parity tests: points indexed, cells, grid origin, 1 / cell, the pruning slack;
  * pts4 = float[n][4] (x, y, z, bitcast point id) in cell order, cell_start = uint32[n_cells + 1] (either may be NULL) */
 int sf_map_index_info(sf_map *m, int64_t *n_indexed, int64_t *n_cells, float org[3], float *inv_h, float *gap_eps);

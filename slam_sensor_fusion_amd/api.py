@@ -356,6 +356,11 @@ class Map:
         _check(self.lib.sf_map_build(self.h, cloud.h, C.c_float(cell)))
         return self
 
+    def set_origin_lattice(self, cells):
+        """sf_map_set_origin_lattice: the grid origin snapped down to a multiple of `cells` cells (0 = off), from the next build on."""
+        _check(self.lib.sf_map_set_origin_lattice(self.h, C.c_int(int(cells))))
+        return self
+
     def patch(self, cloud):
         """sf_map_patch: the index after the last `cloud.voxel_merge(...)`, merged from the old one when it can be; -> True if it was."""
         done = C.c_int(0)

@@ -176,7 +176,8 @@ struct sf_map {
     sf::DevBuf pts4, nrm4, cell_start, keys, vals, keys2, vals2;
     sf::DevBuf pts4_alt, patch_tmp; // sf_map_patch writes the patched index beside the old one and swaps
     double h_exact = 0;       // the cell as sf_map_build chose it
-    float src_mx[3] = {0, 0, 0}; // largest coordinates of the indexed cloud (grid.org holds the smallest)
+    float src_mn[3] = {0, 0, 0}, src_mx[3] = {0, 0, 0}; // bounds of the indexed cloud (grid.org: src_mn, snapped down to the origin lattice if there is one)
+    int origin_lattice = 0;   // sf_map_set_origin_lattice: 0 = the grid starts at the smallest coordinates, n = at the multiple of n cells below them
     uint64_t src_stamp = 0;   // sf_cloud::stamp of the cloud the index describes
     sf::DevBuf d_window; // the window in device memory (REF_CPP kernels read it there: a captured launch list survives a moving crop)
     sf::DevBuf cov6;   // optional: the 6 unique entries of each point's neighbourhood covariance (sorted order), sf_map_estimate_normals

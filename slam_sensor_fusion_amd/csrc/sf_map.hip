@@ -101,6 +101,18 @@ __global__ __launch_bounds__(256) void k_map_nn_t(SfGrid g, SfWindow w, const fl
 } // namespace
 
 namespace {
+// The grid's origin: the smallest coordinate, or -- sf_map_set_origin_lattice -- that coordinate snapped DOWN to a multiple of
+// `lattice` cells, so that a map which grows by a few metres in ANY direction keeps its origin, every point its cell
+// coordinates and the index its order (sf_map_patch).  The result is a float <= mn.
+inline float grid_origin(float mn, double h, int lattice)
+{
+    if (lattice <= 0) return mn;
+    const double step = (double)lattice * h;
+    return (float)(std::floor((double)mn / step) * step);
+}
+
+inline bool table_by_scan(uint64_t ncell, int64_t n_points, int lattice) { return ncell > (1ull << 28) || lattice > 0 || ncell > 16ull * (uint64_t)std::max<int64_t>(n_points, 1); }
+
 // cell_start[0 .. ncell] (+ pads) from the sorted keys of the n_valid indexed points; the buffer is reserved by the caller
 int build_cell_table(sf_map *m, const GridGeom &g, const void *sorted_keys, int64_t n_valid, bool wide, bool by_scan)
 {
@@ -197,12 +209,14 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
     SF_HIP(hipMemGetInfo(&free_b, &total_b));
     const double max_cells = std::min(34359738368.0, std::max(1.0e9, (double)free_b / 4.0 / sizeof(uint32_t)));
     int dim[3];
+    float org[3] = {0, 0, 0};
     for (;;) {
         h = (double)(float)h; // the cell is a float32 everywhere else (sf_map_cell_size, SfGrid::h): a rebuild with the reported cell is the same index
         double cells = 1;
         bool ok = true;
         for (int d = 0; d < 3; ++d) {
-            double c = std::floor(ext[d] / h) + 1;
+            org[d] = n_valid > 0 ? grid_origin(mm.mn[d], h, m->origin_lattice) : 0.0f;
+            double c = std::floor((n_valid > 0 ? (double)mm.mx[d] - (double)org[d] : 0.0) / h) + 1;
             if (c > 2.0e9) ok = false;
             dim[d] = ok ? (int)c : 1;
             cells *= c;
@@ -212,11 +226,13 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
         h *= 1.5;
     }
     GridGeom g;
-    for (int d = 0; d < 3; ++d) { g.org[d] = n_valid > 0 ? mm.mn[d] : 0.0f; g.dim[d] = dim[d]; }
+    for (int d = 0; d < 3; ++d) { g.org[d] = org[d]; g.dim[d] = dim[d]; }
     g.inv_h = (float)(1.0 / h);
     g.ncell = (uint64_t)dim[0] * (uint64_t)dim[1] * (uint64_t)dim[2];
     const bool wide = g.ncell >= 0xffffffffull;     // keys (cell ids, ncell itself for non-finite points) no longer fit 32 bits
-    const bool by_scan = g.ncell > (1ull << 28);    // table large enough for long empty stretches: bounds by scan
+    // long empty stretches -- a large or sparsely filled table, the margin in front of a snapped origin (whole empty layers) --:
+    // bounds by scan (k_cell_bounds has ONE lane walk the gap in front of its point: 0.2 s for 16 M empty cells)
+    const bool by_scan = table_by_scan(g.ncell, n_valid, m->origin_lattice);
 
     // 3. keys -> stable radix sort -> gather
     const size_t np = (size_t)std::max<int64_t>(n, 1), ksz = wide ? sizeof(uint64_t) : sizeof(uint32_t);
@@ -266,7 +282,7 @@ extern "C" int sf_map_build(sf_map *m, sf_cloud *cloud, float cell)
     m->has_cov = false;
     m->generation = sf::next_generation();
     m->h_exact = h;
-    for (int d = 0; d < 3; ++d) m->src_mx[d] = n_valid > 0 ? mm.mx[d] : 0.0f;
+    for (int d = 0; d < 3; ++d) { m->src_mn[d] = n_valid > 0 ? mm.mn[d] : 0.0f; m->src_mx[d] = n_valid > 0 ? mm.mx[d] : 0.0f; }
     m->src_stamp = cloud->stamp;
     return SF_OK;
 }
@@ -450,27 +466,22 @@ extern "C" int sf_map_patch(sf_map *m, sf_cloud *cloud, int *patched)
     if (n_out >= (int64_t)(1 << 28) || old_cells >= 0xffffffffull) return rebuild(SF_PATCH_LIMITS);
 
     // 1. do the bounds of the map survive?  (the merge looked: sf_voxel.hip, k_merge_extremes)
-    float new_mx[3];
+    float new_mn[3], new_mx[3];
     for (int d = 0; d < 3; ++d)
-        if (rec.old_mn[d] != old.org[d] || rec.old_mx[d] != m->src_mx[d]) return rebuild(SF_PATCH_NO_MERGE); // (not the bounds this index was built on)
+        if (rec.old_mn[d] != m->src_mn[d] || rec.old_mx[d] != m->src_mx[d]) return rebuild(SF_PATCH_NO_MERGE); // (not the bounds this index was built on)
     if (rec.touched_extreme) {
         // a point that held a bound was replaced: one reduction over the merged cloud says what the bounds are now (a tenth
-        // of a build); the patch goes on if the smallest coordinates are what they were
+        // of a build)
         sf::MinMaxHost mm;
         SF_TRY(sf::cloud_minmax(ctx, cloud->xyz.as<float>(), n_out, &mm));
         if (mm.n_finite != n_out) return rebuild(SF_PATCH_BOUND_REPLACED);
-        for (int d = 0; d < 3; ++d) { cloud->bounds_mn[d] = mm.mn[d]; cloud->bounds_mx[d] = mm.mx[d]; }
+        for (int d = 0; d < 3; ++d) { cloud->bounds_mn[d] = new_mn[d] = mm.mn[d]; cloud->bounds_mx[d] = new_mx[d] = mm.mx[d]; }
         cloud->bounds_stamp = cloud->stamp; // (the next merge need not look again)
-        for (int d = 0; d < 3; ++d) {
-            if (mm.mn[d] != old.org[d]) return rebuild(SF_PATCH_ORIGIN_MOVED);
-            new_mx[d] = mm.mx[d];
-        }
     } else {
-        for (int d = 0; d < 3; ++d) {
-            if (!(rec.cen_mn[d] > old.org[d])) return rebuild(SF_PATCH_ORIGIN_MOVED); // every cell changes
-            new_mx[d] = std::max(m->src_mx[d], rec.cen_mx[d]);
-        }
+        for (int d = 0; d < 3; ++d) { new_mn[d] = std::min(m->src_mn[d], rec.cen_mn[d]); new_mx[d] = std::max(m->src_mx[d], rec.cen_mx[d]); }
     }
+    for (int d = 0; d < 3; ++d) // the origin a build would choose must be the one the index has: every cell changes otherwise
+        if (grid_origin(new_mn[d], m->h_exact, m->origin_lattice) != old.org[d]) return rebuild(SF_PATCH_ORIGIN_MOVED);
 
     // 2. the geometry a build of the merged cloud would choose (sf_map_build, step 2, explicit cell)
     const double h = m->h_exact;
@@ -492,7 +503,7 @@ extern "C" int sf_map_patch(sf_map *m, sf_cloud *cloud, int *patched)
     if (cells > max_cells || cells >= 4294967295.0) return rebuild(SF_PATCH_LIMITS);
     g.inv_h = pg.inv_h = old.inv_h;
     g.ncell = (uint64_t)g.dim[0] * (uint64_t)g.dim[1] * (uint64_t)g.dim[2];
-    const bool by_scan = g.ncell > (1ull << 28);
+    const bool by_scan = table_by_scan(g.ncell, n_out, m->origin_lattice); // (as sf_map_build)
 
     // 3. the centroids in (cell, id) order; the replaced entries as a bitmap over the old sorted positions
     const int64_t nb256 = sf::div_up(n_old, 256) + 1;
@@ -550,7 +561,7 @@ extern "C" int sf_map_patch(sf_map *m, sf_cloud *cloud, int *patched)
     G.n = n_out;
     m->has_cov = false;
     m->generation = sf::next_generation();
-    for (int d = 0; d < 3; ++d) m->src_mx[d] = new_mx[d];
+    for (int d = 0; d < 3; ++d) { m->src_mn[d] = new_mn[d]; m->src_mx[d] = new_mx[d]; }
     m->src_stamp = cloud->stamp;
     if (patched) *patched = 1;
     return SF_OK;
@@ -578,6 +589,13 @@ extern "C" int sf_map_download_index(sf_map *m, float *pts4, int64_t cap_points,
     if (pts4 && n > 0) SF_HIP(hipMemcpyAsync(pts4, m->pts4.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     if (cell_start) SF_HIP(hipMemcpyAsync(cell_start, m->grid.cell_start, sizeof(uint32_t) * (size_t)nc, hipMemcpyDeviceToHost, ctx->stream));
     SF_HIP(hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+extern "C" int sf_map_set_origin_lattice(sf_map *m, int cells)
+{
+    SF_CHECK(m && cells >= 0 && cells <= 4096, SF_ERR_INVALID, "the lattice is 0 (off) to 4 096 cells");
+    m->origin_lattice = cells; // takes effect with the next sf_map_build
     return SF_OK;
 }
 

@@ -295,6 +295,7 @@ class ImuEkfMappingFlow(EkfLocalizationFlow):
     grow_every_ = 10
     voxel_ = 0.1
     index_stride_ = 1
+    origin_lattice_cells_ = 64
     gyro_sigma_, accel_sigma_ = 2e-3, 5e-2
     gyro_bias_var_, accel_bias_var_ = 1e-4, 1e-2
     gyro_bias_walk_, accel_bias_walk_ = 1e-5, 1e-4
@@ -306,6 +307,7 @@ class ImuEkfMappingFlow(EkfLocalizationFlow):
             self.grow_every_ = int(grow_every)
         self.icp_.set_num_iterations(self.mapping_icp_iterations_)
         self.icp_.set_max_correspondence_dist(self.mapping_max_corr_)
+        self.map_index_.set_origin_lattice(self.origin_lattice_cells_)   # a map that grows: the grid origin survives growth in any direction (sf_map_patch)
         self.index_cloud_ = self.map_cloud_
         if self.index_stride_ != 3:                           # the parent indexed the stride-3 copy
             self.index_cloud_ = api.Cloud(ctx, np.asarray(map_points, dtype=np.float32))

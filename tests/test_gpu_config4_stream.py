@@ -82,7 +82,7 @@ def test_1000_scan_stream_with_imu_ekf_and_map_growth(api, ctx, orc, synth):
                 assert np.array_equal(flow.map_full_.download(), exp), "grown map differs from the oracle at growth step %d" % g0
                 # the index carried over this step (sf_map_patch) is the index a build of the grown map gives, bit for bit
                 cell = flow.map_index_.cell_size()[0]
-                got, want = flow.map_index_.index(), api.Map(ctx, flow.map_full_, cell).index()
+                got, want = flow.map_index_.index(), api.Map(ctx).set_origin_lattice(flow.origin_lattice_cells_).build(flow.map_full_, cell).index()
                 assert all(np.array_equal(got[key].view(np.uint32), want[key].view(np.uint32)) for key in ("pts4", "cell_start", "org")), "index differs from a rebuild at growth step %d" % g0
                 checked += 1
                 snap.clear()

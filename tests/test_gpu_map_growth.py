@@ -128,7 +128,8 @@ def test_index_patch_equals_rebuild(api, ctx, synth):
     """sf_map_patch == sf_map_build of the merged cloud with the same cell (points in cell order with their ids, cell table,
     geometry: bit for bit) over growth steps that touch voxels, open new ones inside and beyond the map's
     upper faces (the grid gets more cells per row: every cell id changes, the order does not), that replace a point which
-    held one of the map's bounds, and the cases that must take the build: the smallest coordinate moves, the cloud was changed between merge and patch, the merge took its full
+    held one of the map's bounds, that reach below its smallest coordinates (with an origin lattice the origin stays), and the
+    cases that must take the build: the origin moves, the cloud was changed between merge and patch, the merge took its full
     path, the index is of another cloud.  setTargetPointCloud after `*map_cloud += *cloud` + VoxelGrid:
     icp_point_to_point.cpp:49-55, global_map_frames_manager.cpp:131,142-146."""
     rng = np.random.default_rng(9)
@@ -139,10 +140,11 @@ def test_index_patch_equals_rebuild(api, ctx, synth):
         dev = api.Cloud(ctx, inner)
         dev.voxel_downsample(0.1, "pcl")
         lo, hi = dev.download().min(0), dev.download().max(0)
-        for cell in (0.25, 0.0):                                      # an explicit cell, and the one the build chooses itself
+        for cell, lattice in ((0.25, 0), (0.0, 0), (0.25, 64)):     # an explicit cell, the one the build chooses itself, an origin lattice (sf_map_set_origin_lattice)
             dev = api.Cloud(ctx, inner)
             dev.voxel_downsample(0.1, "pcl")
-            mp = api.Map(ctx, dev, cell)
+            new_map = lambda cloud, c: api.Map(ctx).set_origin_lattice(lattice).build(cloud, c)
+            mp = new_map(dev, cell)
             h, dims0 = mp.cell_size()
             core = inner[(np.abs(inner[:, 0]) < 5.5) & (np.abs(inner[:, 1]) < 5.5) & (np.abs(inner[:, 2]) < 4.5)]    # (away from the points that hold the map's extremes)
             near = lambda n: (core[rng.choice(len(core), n, replace=False)] + rng.normal(0, 0.004, (n, 3))).astype(np.float32)
@@ -158,20 +160,22 @@ def test_index_patch_equals_rebuild(api, ctx, synth):
                      ("beyond +x / +y / +z", np.concatenate([near(5_000), (rng.uniform(0, 1, (20_000, 3)) * (hi - lo + [3.0, 2.0, 1.0]) + lo + 0.01).astype(np.float32)]), True),
                      ("duplicates", np.repeat(near(200), 30, axis=0), True),
                      ("the point that holds the largest y is replaced", lambda: np.concatenate([near(1_000), (top() - np.float32(0.001))[None]]), True),   # (one reduction for the new bounds, then patched)
-                     ("the point that holds the smallest x is replaced", lambda: np.concatenate([near(1_000), (bottom() + np.float32(0.001))[None]]), False),  # (the origin moves with its centroid)
-                     ("below the origin", np.concatenate([near(1_000), (lo - [0.5, 0.0, 0.0]).astype(np.float32)[None]]), False)]
+                     ("the point that holds the smallest x is replaced", lambda: np.concatenate([near(1_000), (bottom() + np.float32(0.001))[None]]), lattice > 0),  # (the smallest x moves with its centroid: with it the origin, unless that is a lattice point)
+                     ("below the smallest coordinates", np.concatenate([near(1_000), (lo - [0.5, 0.3, 0.2]).astype(np.float32)[None]]), lattice > 0),
+                     ("far below the origin", np.concatenate([near(1_000), (lo - [40.0, 0.0, 0.0]).astype(np.float32)[None]]), False)]
             for name, add, expect in steps:
                 add = add() if callable(add) else add
                 st, merged = dev.voxel_merge(api.Cloud(ctx, add), 0.1)
                 assert st == 0 and merged, name
                 patched = mp.patch(dev)
-                assert patched == expect, (name, cell)
-                ref = api.Map(ctx, dev, h)
+                assert patched == expect, (name, cell, lattice, mp.last_patch)
+                ref = new_map(dev, h)
                 assert _same_index(mp.index(), ref.index()) == "", (name, cell, _same_index(mp.index(), ref.index()))
                 assert mp.cell_size() == ref.cell_size() and len(mp) == len(ref) == len(dev)
                 pts = dev.download()                                  # (the bounds the merge carries over are the bounds of the points)
-                assert np.array_equal(ref.index()["org"], pts.min(0))
-                assert ref.cell_size()[1] == tuple(int(np.floor((float(pts[:, d].max()) - float(pts[:, d].min())) / float(h))) + 1 for d in range(3))
+                org = pts.min(0) if lattice == 0 else (np.floor(pts.min(0).astype(np.float64) / (lattice * float(h))) * (lattice * float(h))).astype(np.float32)
+                assert np.array_equal(ref.index()["org"], org)
+                assert ref.cell_size()[1] == tuple(int(np.floor((float(pts[:, d].max()) - float(org[d])) / float(h))) + 1 for d in range(3))
                 if name.startswith("beyond"):
                     assert mp.cell_size()[1] != dims0                 # more cells per row: the patch renumbered them
             # the patched index answers like the rebuilt one
@@ -184,25 +188,25 @@ def test_index_patch_equals_rebuild(api, ctx, synth):
             assert merged
             dev.transform(np.eye(4, dtype=np.float32))
             assert not mp.patch(dev)
-            assert _same_index(mp.index(), api.Map(ctx, dev, h).index()) == ""
+            assert _same_index(mp.index(), new_map(dev, h).index()) == ""
             # a merge that took the full path (pending empty), then a good one again
             dev.voxel_merge(api.Cloud(ctx, np.zeros((0, 3), np.float32)), 0.1)
             assert not mp.patch(dev)
             st, merged = dev.voxel_merge(api.Cloud(ctx, near(5_000)), 0.1)
             assert merged and mp.patch(dev)
-            assert _same_index(mp.index(), api.Map(ctx, dev, h).index()) == ""
+            assert _same_index(mp.index(), new_map(dev, h).index()) == ""
             # an index of another cloud, and a merge of another cloud in between (the merge tables are the context's)
             other = api.Cloud(ctx, dev.download()[::2].copy())
             other.voxel_downsample(0.1, "pcl")
-            mo = api.Map(ctx, other, h)
+            mo = new_map(other, h)
             st, merged = dev.voxel_merge(api.Cloud(ctx, near(3_000)), 0.1)
             assert merged and not mo.patch(dev)
-            assert _same_index(mo.index(), api.Map(ctx, dev, h).index()) == ""
+            assert _same_index(mo.index(), new_map(dev, h).index()) == ""
             mp.build(dev, h)
             st, merged = dev.voxel_merge(api.Cloud(ctx, near(3_000)), 0.1)
             st2, merged2 = other.voxel_merge(api.Cloud(ctx, near(2_000)), 0.1)
             assert merged and merged2 and not mp.patch(dev)
-            assert _same_index(mp.index(), api.Map(ctx, dev, h).index()) == ""
+            assert _same_index(mp.index(), new_map(dev, h).index()) == ""
     finally:
         api.voxel_merge_min_points(prev)
 
