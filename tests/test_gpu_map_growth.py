@@ -292,3 +292,34 @@ def test_index_patch_edge_cases(api, ctx, synth):
         assert _same_index(a, b) == ""
     finally:
         api.voxel_merge_min_points(prev)
+
+
+@pytest.mark.parametrize("kind", ["dense", "sparse", "lattice"])
+def test_cell_table_is_the_lower_bound_of_the_sorted_keys(api, ctx, synth, kind):
+    """cell_start[c] = first sorted position whose cell id is >= c, for every c in [0, cells] -- checked against numpy on the index as
+    it lies in HBM, for the table built point by point (dense maps), by tails + max-scan (fewer than one point per 16 cells) and
+    behind a snapped origin (sf_map_set_origin_lattice: whole empty layers in front of the data); the points are in (cell, id)
+    order and every point is there once."""
+    rng = np.random.default_rng(31)
+    if kind == "sparse":
+        pts = np.concatenate([c + rng.uniform(0, 3, (5_000, 3)) for c in ([0, 0, 0], [60, 40, 5], [20, 70, 9])]).astype(np.float32)
+    else:
+        pts = synth.make_map(120_000)[:100_000]
+    mp = api.Map(ctx).set_origin_lattice(64 if kind == "lattice" else 0).build(api.Cloud(ctx, pts), 0.25)
+    ix, (h, dims) = mp.index(), mp.cell_size()
+    cells = int(dims[0]) * int(dims[1]) * int(dims[2])
+    if kind != "lattice":
+        assert (cells > 16 * len(pts)) == (kind == "sparse")     # (which builder ran; a lattice always takes the scan)
+    p4 = ix["pts4"]
+    ids = p4[:, 3].copy().view(np.uint32)
+    assert np.array_equal(np.sort(ids), np.arange(len(pts), dtype=np.uint32)) and np.array_equal(p4[:, :3], pts[ids])
+    inv_h = np.float32(ix["inv_h"])
+    c = [np.clip(np.floor((p4[:, d] - ix["org"][d]) * inv_h), 0, dims[d] - 1).astype(np.int64) for d in range(3)]   # float32 arithmetic, as k_cell_keys
+    keys = (c[2] * dims[1] + c[1]) * dims[0] + c[0]
+    assert np.all(np.diff(keys) >= 0) and np.all((np.diff(keys) > 0) | (np.diff(ids.astype(np.int64)) > 0))              # (cell, id) order
+    assert np.array_equal(ix["cell_start"].astype(np.int64), np.searchsorted(keys, np.arange(cells + 1), side="left"))
+    if kind == "lattice":
+        step = 64 * float(h)
+        assert np.array_equal(ix["org"], (np.floor(pts.min(0).astype(np.float64) / step) * step).astype(np.float32))
+    with pytest.raises(api.SlamFusionError):
+        mp.set_origin_lattice(-1)
