@@ -32,6 +32,7 @@
 #include "sf_p2p.hpp"
 
 #include <cfloat>
+#include <cstdlib>
 #include <cmath>
 #include <vector>
 #include <mutex>
@@ -884,6 +885,8 @@ struct CellKeyFn {
     const float *x, *y, *z;
     const IcpState *st;
     int n, shift;
+    const uint16_t *lut; // density-equalised buckets (order_lut_build): key = lut[walk position >> lut_shift], or nullptr
+    int lut_shift;
     // The key is a locality hint, not a result: float32 arithmetic (the pose rounded once per workgroup) puts a
     // query that sits on a bucket border into one of the two buckets, deterministically.
     struct Point { float x, y, z; };
@@ -905,6 +908,7 @@ struct CellKeyFn {
         const int cx = (int)fminf(fmaxf(floorf((qx - g.org[0]) * g.inv_h), 0.0f), (float)(g.dim[0] - 1));
         const int cy = (int)fminf(fmaxf(floorf((qy - g.org[1]) * g.inv_h), 0.0f), (float)(g.dim[1] - 1));
         const int cz = (int)fminf(fmaxf(floorf((qz - g.org[2]) * g.inv_h), 0.0f), (float)(g.dim[2] - 1));
+        if (lut) return (uint32_t)lut[order_cell(g, cx, cy, cz) >> lut_shift];
         const uint64_t key = order_cell(g, cx, cy, cz) >> shift;
         return (uint32_t)(key < (uint64_t)(sf::ORD_KEY_NONE - 1u) ? key : (uint64_t)(sf::ORD_KEY_NONE - 1u));
     }
@@ -913,6 +917,45 @@ struct CellKeyFn {
 __global__ __launch_bounds__(sf::ORD_BLK) void k_order_hist(sf::OrderSrc s, CellKeyFn kf, uint16_t *__restrict__ keys, uint32_t *__restrict__ counts)
 {
     sf::order_hist_body(s, kf, keys, counts);
+}
+
+// Buckets of equal MAP-POINT count instead of equal cell count.  The plain key cuts the walk order into 1 024 stretches of as
+// many cells each: on a map of surfaces most of those are empty and the scan's queries crowd into the few that are not -- the
+// order then resolves little where the points are.  The table maps a fine stretch of the walk order (up to 65 536 of them) to
+// the share of the map's points that lie before it, scaled to the key range: built once per index (sf_icp_set_target*).
+constexpr int ORDER_LUT_LOG2 = 16;
+__global__ __launch_bounds__(256) void k_order_lut_hist(SfGrid g, int lut_shift, uint32_t *__restrict__ hist)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= g.n) return;
+    const float4 p = g.pts[j];
+    const int cx = (int)fminf(fmaxf(floorf((p.x - g.org[0]) * g.inv_h), 0.0f), (float)(g.dim[0] - 1));
+    const int cy = (int)fminf(fmaxf(floorf((p.y - g.org[1]) * g.inv_h), 0.0f), (float)(g.dim[1] - 1));
+    const int cz = (int)fminf(fmaxf(floorf((p.z - g.org[2]) * g.inv_h), 0.0f), (float)(g.dim[2] - 1));
+    atomicAdd(&hist[order_cell(g, cx, cy, cz) >> lut_shift], 1u);
+}
+// one workgroup: exclusive prefix of the histogram -> key of every stretch
+__global__ __launch_bounds__(1024) void k_order_lut_make(const uint32_t *__restrict__ hist, int nbins, uint32_t n_points, uint16_t *__restrict__ lut)
+{
+    __shared__ uint32_t part[1024];
+    const int per = (nbins + 1023) / 1024, a = (int)threadIdx.x * per, b = min(a + per, nbins);
+    uint32_t s = 0;
+    for (int k = a; k < b; ++k) s += hist[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { // Hillis-Steele, inclusive
+        const uint32_t v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint64_t run = part[threadIdx.x] - s;
+    const uint64_t top = (uint64_t)(sf::ORD_KEY_NONE - 1u), n = n_points > 0u ? n_points : 1u;
+    for (int k = a; k < b; ++k) {
+        const uint64_t key = run * top / n;
+        lut[k] = (uint16_t)(key < top ? key : top - 1u);
+        run += hist[k];
+    }
 }
 
 __global__ __launch_bounds__(sf::ORD_BLK) void k_order_scatter(sf::OrderSrc s, const uint16_t *__restrict__ keys, const uint32_t *__restrict__ starts, uint32_t *__restrict__ out)
@@ -2953,6 +2996,9 @@ struct sf_icp {
         std::vector<double> inits_uploaded;
         uint32_t d_inits_epoch = 0xffffffffu;
     } other;
+    sf::DevBuf order_lut;         // k_order_lut_*: histogram (uint32) and key table (uint16) over the walk order of the attached index
+    uint64_t order_lut_gen = 0;   // sf_map::generation the table was built for
+    int order_lut_shift = 0, order_lut_on = 1; // order_lut_on: SF_ORDER_LUT=0 in the environment switches the table off (A/B runs)
     int lane = 0;                 // the lane the members hold
     int pipeline = 1;             // sf_icp_set_pipeline: 0 = every alignment on the context's stream
     hipStream_t lane_stream[2] = {nullptr, nullptr};
@@ -3084,6 +3130,33 @@ bool tile_launch(const sf_icp *icp, int k) { return icp->tile_on && (!icp->reuse
 
 // the segmented stable bucket sort of sf_order.hpp: nseg segments (uniform: nseg scans of icp->n queries; sharded: the
 // owned-query candidates of each scan, seg_off / src_idx on the device), `longest` = the longest segment
+// The key table of the attached index (k_order_lut_*), (re)built when the index has changed.  Enqueued on the context's stream
+// BEFORE an alignment takes a lane: the lanes order themselves behind the context's stream whenever the target changes
+// (LaneScope), so both see the finished table.
+constexpr int ORDER_LUT_BINS = (1 << ORDER_LUT_LOG2) + 1;
+int order_lut_prepare(sf_icp *icp)
+{
+    if (!icp->order_lut_on || !icp->map || !icp->map->built) return SF_OK;
+    const SfGrid &g = icp->map->grid;
+    if (g.n <= 0 || (icp->order_lut.p && icp->order_lut_gen == icp->map->generation)) return SF_OK;
+    const uint64_t ny_pad = ((uint64_t)g.dim[1] + ORDER_YBLK - 1) / ORDER_YBLK * ORDER_YBLK;
+    const uint64_t span = (uint64_t)g.dim[0] * ny_pad * (uint64_t)g.dim[2];
+    int cbits = 0;
+    while (cbits < 63 && (1ull << cbits) < span) ++cbits;
+    icp->order_lut_shift = std::max(0, cbits - ORDER_LUT_LOG2);
+    const int nbins = (int)(span >> icp->order_lut_shift) + 1;
+    SF_TRY(icp->order_lut.reserve(sizeof(uint32_t) * (size_t)ORDER_LUT_BINS + sizeof(uint16_t) * (size_t)ORDER_LUT_BINS));
+    uint32_t *hist = icp->order_lut.as<uint32_t>();
+    uint16_t *lut = reinterpret_cast<uint16_t *>(hist + ORDER_LUT_BINS);
+    hipStream_t st = icp->ctx->stream;
+    SF_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * (size_t)ORDER_LUT_BINS, st));
+    hipLaunchKernelGGL(k_order_lut_hist, dim3(nblk(g.n)), dim3(256), 0, st, g, icp->order_lut_shift, hist);
+    hipLaunchKernelGGL(k_order_lut_make, dim3(1), dim3(1024), 0, st, hist, nbins, (uint32_t)g.n, lut);
+    SF_HIP(hipGetLastError());
+    icp->order_lut_gen = icp->map->generation;
+    return SF_OK;
+}
+
 int run_order_sort(sf_icp *icp, int nseg, int64_t longest, int64_t total, const uint32_t *seg_off, const uint32_t *src_idx)
 {
     const SfGrid &g = icp->map->grid;
@@ -3100,6 +3173,12 @@ int run_order_sort(sf_icp *icp, int nseg, int64_t longest, int64_t total, const 
     (void)all;
     kf.st = icp->state.as<IcpState>();
     kf.shift = order_key_shift(g);
+    kf.lut = nullptr;
+    kf.lut_shift = 0;
+    if (icp->order_lut_on && icp->order_lut.p && icp->order_lut_gen == icp->map->generation) { // (prepared by order_lut_prepare; otherwise the plain key)
+        kf.lut = reinterpret_cast<const uint16_t *>(icp->order_lut.as<uint32_t>() + ORDER_LUT_BINS);
+        kf.lut_shift = icp->order_lut_shift;
+    }
     const size_t cap = (size_t)std::max<int64_t>(total, 1);
     SF_TRY(icp->Xq.reserve(sizeof(float) * 3 * std::max(cap, (size_t)(seg_off ? 0 : icp->plane))));
     SF_TRY(icp->qkeys.reserve(sizeof(uint16_t) * cap));                                                      // bucket key of every element
@@ -3754,6 +3833,7 @@ extern "C" int sf_icp_create(sf_ctx *ctx, float max_correspondence_dist, int num
     icp->prm.num_iters = num_iterations;
     icp->prm.accept = acceptable_mean_error;
     icp->prm.eps = transformation_epsilon;
+    if (const char *e = std::getenv("SF_ORDER_LUT")) icp->order_lut_on = std::atoi(e) != 0;
     *out = icp;
     return SF_OK;
 }
@@ -4191,6 +4271,7 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     SF_HIP(hipSetDevice(icp->ctx->device));
     icp->last_mode = mode;
     icp->last_fused = fused_eligible(icp, mode);
+    SF_TRY(order_lut_prepare(icp));
     // the launch list takes a lane (see sf_icp::Lane); the single launch, profiled runs and a count left on the device stay on the context's stream
     LaneScope lanes(icp, icp->pipeline != 0 && !icp->last_fused && !icp->profiling && !icp->n_on_device);
     SF_TRY(lanes.rc);
@@ -4379,6 +4460,7 @@ extern "C" int sf_icp_step_begin(sf_icp *icp, int mode, int first)
     SF_HIP(hipSetDevice(icp->ctx->device));
     icp->last_mode = mode;
     icp->last_fused = false;
+    if (first) SF_TRY(order_lut_prepare(icp));
     if (first == 1) SF_TRY(launch_state_init(icp));
     if (icp->shard) {
         if (first) SF_TRY(shard_build(icp, first == 2));
@@ -4493,6 +4575,7 @@ int shard_step_p2p(sf_icp *icp, int mode, int first, const sf::P2pView &view)
     SF_HIP(hipSetDevice(icp->ctx->device));
     icp->last_mode = mode;
     icp->last_fused = false;
+    if (first) SF_TRY(order_lut_prepare(icp));
     if (first == 1) SF_TRY(launch_state_init(icp));
     if (first) SF_TRY(shard_build(icp, first == 2));
     if (first) SF_TRY(freeze_start_pass(icp, mode));
