@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--query-order", default="auto", choices=["auto", "as_given", "cell"], help="sf_icp_set_query_order")
     ap.add_argument("--no-nn-reuse", action="store_true", help="sf_icp_set_nn_reuse(0): search every query in every iteration")
     ap.add_argument("--no-freeze", action="store_true", help="sf_icp_set_freeze(0): every launch of an alignment streams every query (rounds 1-3 up to here)")
+    ap.add_argument("--freeze-params", default="", help="experiment: guard_scale,guard_min,guard_max,max_tries,from_launch for sf_icp_set_freeze_params (default: the library's)")
     ap.add_argument("--force-freeze", action="store_true", help="sf_icp_set_freeze(2): frozen pairs for batches below the automatic threshold (0.7 M queries) too")
     ap.add_argument("--tile", action="store_true", help="sf_icp_set_tile_search(always): the searching launches served out of LDS tile by tile (sf_tile.hpp; measured "
                                                         "slower than the walk through the global grid index, which stays the default)")
@@ -210,6 +211,9 @@ def main():
         icp.set_freeze(False if args.no_freeze else (True if args.force_freeze else "auto"))
         icp.set_tile_search("always" if args.tile else False)
         icp.set_pipeline(not args.no_pipeline)
+        if args.freeze_params:
+            gs, gmin, gmax, tries, frm = args.freeze_params.split(",")
+            icp.set_freeze_params(float(gs), float(gmin), float(gmax), int(tries), int(frm))
         return icp
 
     # ---------------- the registration driver of this rank

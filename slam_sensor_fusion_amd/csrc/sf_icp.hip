@@ -3577,11 +3577,11 @@ int enqueue_align(sf_icp *icp, int mode)
             if (fz && k >= icp->fz_from) launch_nn_red_fz(icp, false, k > icp->fz_from);
             else if (tile_launch(icp, k)) launch_tile_search<2>(icp, q1);
             else launch_nn_red<2>(icp, false, q1);
-            if (q1)
+            if (fz && k + 1 >= icp->fz_from) // (after a one-query-per-lane launch too: an ordinary record of twice as many rows, and the solve may ask for the freeze launch)
+                hipLaunchKernelGGL(k_reduce_solve_fz, dim3(B), dim3(RBLK), 0, s, st, part, q1 ? icp->nblocks : icp->nblocks_nn, n, K, icp->d_boxes.as<ScanBox>(), freeze_bufs(icp, true),
+                                   icp->fz_prm, (int)(k + 2 < K));
+            else if (q1)
                 hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks, n, k, K, icp->d_boxes.as<ScanBox>());
-            else if (fz && k + 1 >= icp->fz_from)
-                hipLaunchKernelGGL(k_reduce_solve_fz, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, K, icp->d_boxes.as<ScanBox>(), freeze_bufs(icp, true), icp->fz_prm,
-                                   (int)(k + 2 < K));
             else
                 hipLaunchKernelGGL(k_reduce_solve<2>, dim3(B), dim3(RBLK), 0, s, st, part, icp->nblocks_nn, n, k, K, icp->d_boxes.as<ScanBox>());
         }
