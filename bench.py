@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--query-order", default="auto", choices=["auto", "as_given", "cell"], help="sf_icp_set_query_order")
     ap.add_argument("--no-nn-reuse", action="store_true", help="sf_icp_set_nn_reuse(0): search every query in every iteration")
     ap.add_argument("--no-freeze", action="store_true", help="sf_icp_set_freeze(0): every launch of an alignment streams every query (rounds 1-3 up to here)")
+    ap.add_argument("--deliver", default="all", choices=["all", "last"],
+                    help="all: every step's results are fetched inside the timed region (sf_icp_fetch_previous: the step before, while this one runs); last: only the last step's, after it")
     ap.add_argument("--freeze-params", default="", help="experiment: guard_scale,guard_min,guard_max,max_tries,from_launch for sf_icp_set_freeze_params (default: the library's)")
     ap.add_argument("--force-freeze", action="store_true", help="sf_icp_set_freeze(2): frozen pairs for batches below the automatic threshold (0.7 M queries) too")
     ap.add_argument("--tile", action="store_true", help="sf_icp_set_tile_search(always): the searching launches served out of LDS tile by tile (sf_tile.hpp; measured "
@@ -433,10 +435,24 @@ def main():
     setup_s = time.time() - t_setup
 
     results_box = {}
+    # Every step's results reach the host inside the timed region (--deliver all, the default): the streaming loop of
+    # include/slamfusion.h -- enqueue this step's alignment, then fetch the PREVIOUS step's results (sf_icp_fetch_previous waits for
+    # that alignment only, this one goes on running on the other lane); with one lane (--no-pipeline) every step is fetched before
+    # the next is enqueued.  --deliver last: only the last step's results are fetched, after the timed region (rounds 1-3).
+    delivered = []
+    lanes_on = routed is None and not args.no_pipeline
+    deliver_all = routed is None and args.deliver == "all"
+    enq = {"n": 0}
 
-    def step():
+    def step(deliver=False):
         if routed is None:
             icp.align_batch_async(args.mode)
+            enq["n"] += 1
+            if deliver_all and deliver:
+                if not lanes_on:
+                    delivered.append(icp.fetch_results(raw=True))
+                elif enq["n"] > 1:
+                    delivered.append(icp.fetch_previous(raw=True))
         else:
             results_box["r"] = routed.align(args.mode)    # blocking per group: resumes are decided on fetched states
 
@@ -446,11 +462,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        step(True)
     barrier()
+    del delivered[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -463,14 +480,26 @@ def main():
         elapsed = float(t.item())
     if routed is None:
         results = dict(enumerate(icp.fetch_results()))
+        # what was delivered inside the timed region (with the lanes: every step but the last, whose fetch is the line above, plus the
+        # last warm-up step's): the same inputs every step, so every delivered pose must be the last step's, bit for bit
+        delivered_ok = all(np.array_equal(np.array(arr[b].T64), results[b]["T64"].ravel()) and arr[b].iterations == results[b]["iterations"]
+                           for arr in delivered for b in range(B))
+        delivery = {"mode": args.deliver if deliver_all else "last", "results_fetched_in_timed_region": len(delivered) * B,
+                    "how": ("sf_icp_fetch_previous after every enqueue (two lanes)" if lanes_on else "sf_icp_fetch_results after every enqueue (one lane)") if deliver_all else None,
+                    "all_equal_to_last": bool(delivered_ok)}
+        if not delivered_ok:
+            print("bench: a delivered result differs from the last step's", file=sys.stderr)
     else:
         results = results_box["r"]
+        delivery = {"mode": "all", "how": "sf_icp_align_sharded fetches every step (blocking)"}
 
     # ---------------- correctness of what was timed: the registrations against the generating transform
     terr = max(synth.pose_error(r["T64"], synth.t_true())[0] for r in results.values()) if results else 0.0
     rerr = max(synth.pose_error(r["T64"], synth.t_true())[1] for r in results.values()) if results else 0.0
     truth_bar = (0.05, 5e-3) if args.mode == "ref_cpp" else (5e-3, 5e-4)   # ref_cpp stops at its 5 cm mean-error rule
     ok_truth = all(r["iterations"] == iters or args.mode != "p2plane" for r in results.values()) and terr < truth_bar[0] and rerr < truth_bar[1]
+    if routed is None:
+        ok_truth = ok_truth and delivered_ok   # (a delivered result that is not the last step's, bit for bit, fails the run)
 
     # ---------------- the dominant kernel (fused transform + NN + accumulate; ref_cpp: the search kernel), HIP events per launch
     prof = None
@@ -706,6 +735,28 @@ def main():
         extras["value_upload_inclusive"] = B * k / (time.perf_counter() - t1)
         extras["upload_bytes_per_step"] = int(scans.nbytes)
         up.close()
+        # the same through the library alone -- the streaming loop of include/slamfusion.h: set the next batch from (pinned) host
+        # memory, enqueue its alignment, fetch the previous batch's results.  With an alignment in flight the upload and the
+        # conversion take the other source set on the next lane's stream (sf_icp.hip, SrcScope): they run beside the alignment,
+        # and every result reaches the host.  Two host buffers take turns (what a sensor driver's double buffer does).
+        if not args.no_pipeline:
+            pinned2 = [pinned, torch.from_numpy(scans.copy()).pin_memory()]
+            st = new_icp()
+            st.set_source_batch_host_ptr(pinned2[0].data_ptr(), n_scan, B)
+            st.set_initial_batch(None)
+            first = st.align_batch(args.mode)
+            t1 = time.perf_counter()
+            got = []
+            for s_ in range(k):
+                st.set_source_batch_host_ptr(pinned2[s_ % 2].data_ptr(), n_scan, B)
+                st.align_batch_async(args.mode)
+                if s_ > 0:
+                    got.append(st.fetch_previous(raw=True))
+            got.append(st.fetch_results(raw=True))
+            extras["value_stream_upload_inclusive"] = B * k / (time.perf_counter() - t1)
+            extras["stream_results_delivered"] = len(got) * B
+            extras["stream_results_equal"] = bool(all(np.array_equal(np.array(a[b].T64), first[b]["T64"].ravel()) for a in got for b in range(B)))
+            st.close()
         for c_ in staging:
             c_.close()
         copy_ctx.close()
@@ -964,6 +1015,8 @@ def main():
         "value_tile_search": extras.get("value_tile_search"),
         "value_city": extras.get("value_city"),
         "value_upload_inclusive": extras.get("value_upload_inclusive"),
+        "value_stream_upload_inclusive": extras.get("value_stream_upload_inclusive"),
+        "stream_results": {"delivered": extras.get("stream_results_delivered"), "all_equal": extras.get("stream_results_equal")},
         "value_32_in_flight": extras.get("value_32_in_flight"),
         "value_stream_config4": extras.get("value_stream_config4"),
         "higher_is_better": True,
@@ -989,6 +1042,7 @@ def main():
                    "collective": (coll_info or {}).get("kind"),
                    "shard_resumes": (routed.resumes if routed is not None else 0),
                    "routing_groups": ({"%d-%d" % k: len(v) for k, v in routed.groups.items()} if routed is not None else None)},
+        "delivery": delivery,
         "parity": {"max_translation_err_vs_truth_m": terr, "max_rotation_err_vs_truth_rad": rerr, "ok": bool(ok_truth)},
         "roofline": roof if roof is not None else roof_dist,
         "setup_s": setup_s,

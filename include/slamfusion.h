@@ -269,9 +269,19 @@ int sf_icp_set_source_batch(sf_icp *icp, const float *xyz, int64_t n_per_scan, i
 int sf_icp_set_source_batch_device(sf_icp *icp, const void *d_xyz, int64_t n_per_scan, int batch);
 int sf_icp_set_initial_batch_f64(sf_icp *icp, const double *inits);
 int sf_icp_align_batch(sf_icp *icp, int mode, sf_icp_result *out /* batch entries */);
-/* enqueue only (no host sync); results fetched later */
+/* enqueue only (no host sync); results fetched later.  sf_icp_fetch_results returns the LATEST enqueued alignment as it
+ * was enqueued (`out`: as many entries as ITS batch) -- a source or priors set since belong to the next alignment. */
 int sf_icp_align_batch_async(sf_icp *icp, int mode);
 int sf_icp_fetch_results(sf_icp *icp, sf_icp_result *out);
+/* The results of the alignment enqueued BEFORE the latest one, when the two ran side by side (two
+ * sf_icp_align_batch_async calls with no fetch between them, sf_icp_set_pipeline on, launch list): waits for that
+ * alignment only, the latest one goes on running.  The streaming loop is "set the next batch, enqueue its alignment,
+ * fetch the previous one's result": every result reaches the host and the device never drains.  `out`: as many
+ * entries as THAT alignment's batch.  SF_ERR_STATE when there is nothing to fetch: the latest alignment did not run
+ * beside its predecessor (a fetch in between, pipeline off, a single-launch or profiled alignment) -- then the
+ * predecessor's states have been overwritten -- or the call was made already.  No reference counterpart (one scan per
+ * callback, localization_node.cpp:337). */
+int sf_icp_fetch_previous(sf_icp *icp, sf_icp_result *out);
 int sf_icp_use_graph(sf_icp *icp, int on); /* replay the launch sequence as a hipGraph */
 /* how often the launch sequence was captured / launched as a graph since creation (a capture per alignment means the
  * cache key keeps changing).  REF_CPP with ONE scan reads the scan's point count and the map window from device memory,
@@ -320,6 +330,12 @@ int sf_icp_set_wide_scan_points(sf_icp *icp, int64_t points);
  * enqueued: a fetch, an upload or a map rebuild issued afterwards is ordered behind it exactly as before, and a changed input
  * makes the next alignment wait for everything before it.  A caller that fetches each result before the next alignment never
  * leaves the context's stream.  Results are those of the same alignment run alone (same kernels, same data; tested bitwise).
+ * A source set FROM HOST MEMORY (sf_icp_set_source_batch / sf_icp_set_source) while an alignment is unfetched does not wait
+ * for it either: the object keeps two source sets, the upload and its conversion take the one the alignment in flight does
+ * not read, on the stream the next alignment will run on -- the streaming loop "set the next batch, enqueue its alignment,
+ * sf_icp_fetch_previous" uploads batch k+1 beside the alignment of batch k (measured: +11 % over the same loop with the
+ * upload behind the alignment; profiles/LADDER.md).  Sources handed over as DEVICE pointers or clouds stay on the context's
+ * stream, behind whatever produced them.
  * on: 1 (default) / 0 = every alignment on the context's stream.  No reference counterpart (one scan at a time,
  * localization_node.cpp:337). */
 int sf_icp_set_pipeline(sf_icp *icp, int on);

@@ -609,15 +609,26 @@ class Icp:
     def align_batch(self, mode="p2plane"):
         arr = (IcpResult * self.batch)()
         _check(self.lib.sf_icp_align_batch(self.h, C.c_int(MODES[mode]), arr))
+        self._prev_batch, self._last_batch = getattr(self, "_last_batch", None), self.batch
         return [r.as_dict() for r in arr]
 
     def align_batch_async(self, mode="p2plane"):
         _check(self.lib.sf_icp_align_batch_async(self.h, C.c_int(MODES[mode])))
+        # how many scans the latest / the previous enqueued alignment registered (a source set since belongs to the next one)
+        self._prev_batch, self._last_batch = getattr(self, "_last_batch", None), self.batch
 
-    def fetch_results(self):
-        arr = (IcpResult * self.batch)()
+    def fetch_results(self, raw=False):
+        """Results of the LATEST enqueued alignment, as it was enqueued."""
+        arr = (IcpResult * int(getattr(self, "_last_batch", None) or self.batch))()
         _check(self.lib.sf_icp_fetch_results(self.h, arr))
-        return [r.as_dict() for r in arr]
+        return arr if raw else [r.as_dict() for r in arr]
+
+    def fetch_previous(self, batch=None, raw=False):
+        """Results of the alignment enqueued before the latest one (both asynchronous, no fetch between them): waits for that
+        one only; raw: the ctypes array as it came."""
+        arr = (IcpResult * int(batch or getattr(self, "_prev_batch", None) or self.batch))()
+        _check(self.lib.sf_icp_fetch_previous(self.h, arr))
+        return arr if raw else [r.as_dict() for r in arr]
 
     # multi-GPU stepping
     def set_shard(self, x_lo, x_hi):

@@ -1944,24 +1944,28 @@ __global__ __launch_bounds__(BLK, NN_RED_WAVES) void k_nn_red_fz_few(SfGrid g, S
 
 // fixed-order column sums of a slab with rows of STRIDE doubles, NCOL columns (NCOL <= 128), by NT threads (a multiple of
 // 128): thread (slice s of NT / 128, column c of 128) adds rows s, s + NT / 128, ...; the slices are then added in order
+// (NS = 8 slices whatever NT: a workgroup of fewer than 1024 threads takes several slices per thread, one after the other --
+// every (slice, column) sum is the same expression, so the result is bit-identical for every NT, as reduce_partials')
 template <int STRIDE, int NCOL, int NT>
 __device__ __forceinline__ void reduce_columns(const double *__restrict__ part, int nrows, double *out)
 {
-    constexpr int NS = NT / 128;
-    static_assert(NT % 128 == 0 && NS >= 1 && NCOL <= 128, "slices of 128 columns");
+    constexpr int NS = 8;
+    static_assert(NT % 128 == 0 && NT / 128 >= 1 && NT / 128 <= NS && NCOL <= 128, "slices of 128 columns");
     __shared__ double sl[NS][128];
-    const int c = threadIdx.x & 127, sidx = threadIdx.x >> 7;
-    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-    if (c < NCOL) {
-        int r = sidx;
-        for (; r + 3 * NS < nrows; r += 4 * NS) {
-            const double a0 = part[(size_t)r * STRIDE + c], a1 = part[(size_t)(r + NS) * STRIDE + c];
-            const double a2 = part[(size_t)(r + 2 * NS) * STRIDE + c], a3 = part[(size_t)(r + 3 * NS) * STRIDE + c];
-            v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+    const int c = threadIdx.x & 127;
+    for (int sidx = threadIdx.x >> 7; sidx < NS; sidx += NT / 128) {
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        if (c < NCOL) {
+            int r = sidx;
+            for (; r + 3 * NS < nrows; r += 4 * NS) {
+                const double a0 = part[(size_t)r * STRIDE + c], a1 = part[(size_t)(r + NS) * STRIDE + c];
+                const double a2 = part[(size_t)(r + 2 * NS) * STRIDE + c], a3 = part[(size_t)(r + 3 * NS) * STRIDE + c];
+                v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+            }
+            for (; r < nrows; r += NS) v0 += part[(size_t)r * STRIDE + c];
         }
-        for (; r < nrows; r += NS) v0 += part[(size_t)r * STRIDE + c];
+        sl[sidx][c] = (v0 + v1) + (v2 + v3);
     }
-    sl[sidx][c] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (threadIdx.x < NCOL) {
         double v = 0;
@@ -2996,6 +3000,28 @@ struct sf_icp {
         std::vector<double> inits_uploaded;
         uint32_t d_inits_epoch = 0xffffffffu;
     } other;
+    // Two SOURCE SETS (the members hold one, `other_src` the other): a source set while an alignment of this object is still
+    // unfetched goes into the set that alignment does not read, on the stream of the lane the next alignment will take, so the
+    // next batch's upload / conversion runs beside the alignment in flight instead of behind it (SrcScope).  Per set an event
+    // marks the end of the last alignment that read it; `src_ready` the end of the last upload that ran on a lane's stream.
+    struct SrcSet {
+        sf::DevBuf X0, X0r, stage, d_boxes, d_box_parts, n_dev;
+        int64_t n = 0, n_cap = 0, plane = 0;
+        int batch = 0, nblocks = 0, nblocks_nn = 0, qpl = 1;
+        bool have_source = false, n_on_device = false;
+    } other_src;
+    int src_set = 0;              // which set the members hold
+    hipEvent_t src_used[2] = {nullptr, nullptr}, src_ready = nullptr;
+    bool src_used_rec[2] = {false, false};
+    bool src_ahead = false;       // the members' source was written on a lane's stream (src_ready) and no alignment has been ordered behind it yet
+    // what the lane's last alignment was (sf_icp_fetch_previous reads the OTHER lane's states with the other lane's description)
+    struct LaneMeta {
+        bool valid = false;
+        int batch = 0, mode = 0;
+        std::vector<double> inits;
+    } meta, other_meta;
+    bool prev_ok = false;         // the alignment before the latest one ran on the other lane and has not been overwritten or fetched
+    std::vector<IcpState> h_prev;
     sf::DevBuf order_lut;         // k_order_lut_*: histogram (uint32) and key table (uint16) over the walk order of the attached index
     uint64_t order_lut_gen = 0;   // sf_map::generation the table was built for
     int order_lut_shift = 0, order_lut_on = 1; // order_lut_on: SF_ORDER_LUT=0 in the environment switches the table off (A/B runs)
@@ -3009,7 +3035,6 @@ struct sf_icp {
     uint64_t src_version = 0, mark_src_version = 0, mark_map_generation = 0;
     const void *mark_map = nullptr;
     SfWindow mark_window{};
-    std::vector<double> mark_inits;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> ev;
@@ -3256,7 +3281,81 @@ int order_queries(sf_icp *icp, int mode)
     return SF_OK;
 }
 
-int icp_alloc(sf_icp *icp, int64_t n, int batch)
+void raw_swap(sf::DevBuf &a, sf::DevBuf &b) // the allocations change places, epochs included (a captured graph keeps pointing at ITS lane's buffers)
+{
+    std::swap(a.p, b.p);
+    std::swap(a.cap, b.cap);
+    std::swap(a.epoch, b.epoch);
+}
+
+void src_flip(sf_icp *icp)
+{
+    sf_icp::SrcSet &o = icp->other_src;
+    raw_swap(icp->X0, o.X0); raw_swap(icp->X0r, o.X0r); raw_swap(icp->stage, o.stage); raw_swap(icp->d_boxes, o.d_boxes); raw_swap(icp->d_box_parts, o.d_box_parts);
+    raw_swap(icp->n_dev, o.n_dev);
+    std::swap(icp->n, o.n); std::swap(icp->n_cap, o.n_cap); std::swap(icp->plane, o.plane);
+    std::swap(icp->batch, o.batch); std::swap(icp->nblocks, o.nblocks); std::swap(icp->nblocks_nn, o.nblocks_nn); std::swap(icp->qpl, o.qpl);
+    std::swap(icp->have_source, o.have_source); std::swap(icp->n_on_device, o.n_on_device);
+    icp->src_set ^= 1;
+}
+
+// the lanes' streams and every event of the pipeline, once
+int ensure_lanes(sf_icp *icp)
+{
+    for (int l = 0; l < 2; ++l) {
+        if (!icp->lane_stream[l]) SF_HIP(hipStreamCreateWithFlags(&icp->lane_stream[l], hipStreamNonBlocking));
+        if (!icp->lane_done[l]) SF_HIP(hipEventCreateWithFlags(&icp->lane_done[l], hipEventDisableTiming));
+        if (!icp->src_used[l]) SF_HIP(hipEventCreateWithFlags(&icp->src_used[l], hipEventDisableTiming));
+    }
+    if (!icp->main_mark) SF_HIP(hipEventCreateWithFlags(&icp->main_mark, hipEventDisableTiming));
+    if (!icp->src_ready) SF_HIP(hipEventCreateWithFlags(&icp->src_ready, hipEventDisableTiming));
+    return SF_OK;
+}
+
+// RAII around a call that writes the source.  While an alignment of this object is unfetched (and the lanes are on) the new
+// source goes into the OTHER source set, on the stream of the lane the next alignment will take: it waits for the last
+// alignment that read that set, not for the alignment in flight.  Otherwise: the set at hand on the context's stream, as before.
+struct SrcScope {
+    sf_icp *icp;
+    hipStream_t main = nullptr;
+    bool ahead = false;
+    uint64_t version0 = 0;
+    int rc = SF_OK;
+    SrcScope(sf_icp *i, bool allowed) : icp(i)
+    {
+        main = icp->ctx->stream;
+        version0 = icp->src_version;
+        static const bool ahead_on = []() { const char *e = std::getenv("SF_SRC_AHEAD"); return !e || std::atoi(e) != 0; }(); // (A/B switch)
+        const bool go = ahead_on && allowed && icp->pipeline != 0 && icp->unfetched && !icp->shard && !icp->profiling;
+        if (!go) {
+            // the set at hand on the context's stream: behind an upload that went to a lane's stream, if there was one
+            if (icp->src_ahead) {
+                if (hipStreamWaitEvent(main, icp->src_ready, 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
+                icp->src_ahead = false;
+            }
+            return;
+        }
+        rc = ensure_lanes(icp);
+        if (rc != SF_OK) return;
+        if (!icp->src_ahead) src_flip(icp); // (a second source before any alignment: the same set, the same stream, again)
+        hipStream_t ls = icp->lane_stream[icp->lane ^ 1];
+        if (icp->src_used_rec[icp->src_set] && hipStreamWaitEvent(ls, icp->src_used[icp->src_set], 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
+        icp->ctx->stream = ls;
+        ahead = true;
+    }
+    ~SrcScope()
+    {
+        hipStream_t ran = icp->ctx->stream;
+        icp->ctx->stream = main;
+        if (!ahead) return;
+        if (hipEventRecord(icp->src_ready, ran) == hipSuccess) icp->src_ahead = true;
+        // (this source did not pass the context's stream: the mark of the inputs that did stands as it stood)
+        if (icp->mark_valid && icp->mark_src_version == version0) icp->mark_src_version = icp->src_version;
+    }
+};
+
+// outputs = false (a source written ahead of an alignment in flight): the lane's output buffers are left to lane_reserve at the next enqueue
+int icp_alloc(sf_icp *icp, int64_t n, int batch, bool outputs = true)
 {
     const int64_t total = n * batch;
     // plane = distance between the x, y and z components of the SoA arrays: rounded up and never shrinking, so that the
@@ -3264,8 +3363,12 @@ int icp_alloc(sf_icp *icp, int64_t n, int batch)
     icp->plane = std::max<int64_t>(icp->plane, sf::div_up(std::max<int64_t>(total, 1), 4096) * 4096);
     SF_TRY(icp->X0.reserve(sizeof(float) * 3 * (size_t)icp->plane));
     SF_TRY(icp->X0r.reserve(sizeof(float4) * (size_t)icp->plane));
-    SF_TRY(icp->state.reserve(sizeof(IcpState) * (size_t)batch));
-    SF_TRY(icp->d_inits.reserve(sizeof(double) * 16 * (size_t)batch));
+    if (outputs) {
+        const auto e0 = icp->state.epoch;
+        SF_TRY(icp->state.reserve(sizeof(IcpState) * (size_t)batch));
+        if (icp->state.epoch != e0) icp->meta.valid = false; // (the states of this lane's last alignment went with the old allocation: sf_icp_fetch_previous has nothing to read)
+        SF_TRY(icp->d_inits.reserve(sizeof(double) * 16 * (size_t)batch));
+    }
     // single scan: workgroups for the point count rounded up to 4096 (the kernels bound themselves by the count in
     // device memory), so the launch geometry -- and with it a captured graph -- is shared by scans of similar size
     icp->n_cap = batch == 1 ? sf::div_up(std::max<int64_t>(n, 1), 4096) * 4096 : n;
@@ -3280,8 +3383,10 @@ int icp_alloc(sf_icp *icp, int64_t n, int batch)
     }
     icp->qpl = wide ? SF_WIDE_QPL : 1;
     icp->nblocks_nn = (int)std::max<int64_t>(1, sf::div_up(n, BLK * icp->qpl));
-    SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)REC_STRIDE * (size_t)icp->nblocks * (size_t)batch));
-    SF_TRY(icp->xchg_own.reserve(sizeof(double) * REC_STRIDE * (size_t)batch));
+    if (outputs) {
+        SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)REC_STRIDE * (size_t)icp->nblocks * (size_t)batch));
+        SF_TRY(icp->xchg_own.reserve(sizeof(double) * REC_STRIDE * (size_t)batch));
+    }
     if (icp->batch != batch || icp->inits.size() != (size_t)batch * 16) {
         icp->inits.assign((size_t)batch * 16, 0.0);
         for (int b = 0; b < batch; ++b)
@@ -3293,9 +3398,9 @@ int icp_alloc(sf_icp *icp, int64_t n, int batch)
     return SF_OK;
 }
 
-int icp_set_source_device_aos(sf_icp *icp, const float *d_aos, int64_t n, int batch)
+int icp_set_source_device_aos(sf_icp *icp, const float *d_aos, int64_t n, int batch, bool ahead = false)
 {
-    SF_TRY(icp_alloc(icp, n, batch));
+    SF_TRY(icp_alloc(icp, n, batch, !ahead));
     icp->n_on_device = false;
     const int64_t total = n * batch;
     if (total > 0)
@@ -3304,13 +3409,9 @@ int icp_set_source_device_aos(sf_icp *icp, const float *d_aos, int64_t n, int ba
     SF_TRY(icp->n_dev.reserve(sizeof(int)));
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, icp->ctx->stream, icp->n_dev.as<int>(), (int)n);
     SF_HIP(hipGetLastError());
-    // bounding box of the batch (the sharded path's list-rebuild rule reads it in k_solve_only): reduced on the
-    // device and left there -- no host synchronisation per scan
-    static_assert(sizeof(ScanBox) <= sizeof(sf::MinMaxDev), "ScanBox is the head of MinMaxDev");
-    SF_TRY(icp->d_box.reserve(sizeof(sf::MinMaxDev)));
-    SF_TRY(sf::cloud_minmax_enqueue(icp->ctx, d_aos, total, icp->d_box.as<sf::MinMaxDev>()));
-    // ... and of every scan on its own: what moves a scan's points is bounded by ITS box (a batch of 10 m scans spread over a
-    // 100 m map has a 100 m box and every rotation a 50 m lever arm)
+    // bounding box of every scan on its own, reduced on the device and left there (no host synchronisation per scan): what moves
+    // a scan's points is bounded by ITS box (a batch of 10 m scans spread over a 100 m map has a 100 m box and every rotation a
+    // 50 m lever arm).  (The box of the whole batch, which rounds 1-3 also formed here, had no reader left.)
     SF_TRY(icp->d_boxes.reserve(sizeof(ScanBox) * (size_t)std::max(batch, 1)));
     SF_TRY(icp->d_box_parts.reserve(sizeof(ScanBox) * BOX_PARTS * (size_t)std::max(batch, 1)));
     hipLaunchKernelGGL(k_scan_boxes_partial, dim3(BOX_PARTS, (unsigned)std::max(batch, 1)), dim3(256), 0, icp->ctx->stream, soa(icp->X0, icp->plane, 0), soa(icp->X0, icp->plane, 1),
@@ -3370,7 +3471,7 @@ sf_icp::GraphKey graph_key_now(const sf_icp *icp, int mode)
     const sf::DevBuf *bufs[] = {&icp->X0, &icp->X0r, &icp->X, &icp->Xq, &icp->qcache, &icp->corr, &icp->state, &icp->partials, &icp->d_box, &icp->d_boxes, &icp->n_dev,
                                 &icp->map->pts4, &icp->map->nrm4, &icp->map->cell_start, &icp->map->d_window, &icp->fz_state, &icp->fz_part, &icp->fz_cnt, &icp->fz_ids, &icp->fz_all, &icp->tseg, &icp->tile_stats};
     k.epochs = (uint64_t)icp->plane;
-    for (const sf::DevBuf *b : bufs) k.epochs = k.epochs * 1000003ull + b->epoch;
+    for (const sf::DevBuf *b : bufs) k.epochs = (k.epochs * 1000003ull + b->epoch) * 1000003ull + (uint64_t)(uintptr_t)b->p; // (the address too: the two source sets take turns under one lane's graph)
     return k;
 }
 
@@ -3800,15 +3901,18 @@ void fill_result(const sf_icp *icp, int mode, const IcpState &S, const double *i
 // the states of the last alignment on the host: copied back, or -- single-launch forms -- already written to pinned host
 // memory by the kernel itself (measured on the per-scan path: enqueueing the 608-byte copy costs more host time than the
 // kernel's stores)
-int states_to_host(sf_icp *icp)
+// count: the scans of the alignment whose states are fetched (-1: the current source's -- the stepping / sharded paths)
+int states_to_host(sf_icp *icp, int count = -1)
 {
     hipStream_t s = icp->ctx->stream;
+    const size_t nb = (size_t)(count >= 0 ? count : icp->batch);
+    if (icp->h_state.size() < nb) icp->h_state.resize(nb);
     if (icp->last_fused && icp->h_pin) {
         SF_HIP(hipStreamSynchronize(s));
-        std::memcpy(icp->h_state.data(), icp->h_pin, sizeof(IcpState) * (size_t)icp->batch);
+        std::memcpy(icp->h_state.data(), icp->h_pin, sizeof(IcpState) * nb);
         return SF_OK;
     }
-    SF_HIP(hipMemcpyAsync(icp->h_state.data(), icp->state.p, sizeof(IcpState) * (size_t)icp->batch, hipMemcpyDeviceToHost, s));
+    SF_HIP(hipMemcpyAsync(icp->h_state.data(), icp->state.p, sizeof(IcpState) * nb, hipMemcpyDeviceToHost, s));
     SF_HIP(hipStreamSynchronize(s));
     return SF_OK;
 }
@@ -3849,7 +3953,9 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
     for (int l = 0; l < 2; ++l) {
         if (icp->lane_stream[l]) { e = hipStreamSynchronize(icp->lane_stream[l]); (void)e; e = hipStreamDestroy(icp->lane_stream[l]); (void)e; }
         if (icp->lane_done[l]) { e = hipEventDestroy(icp->lane_done[l]); (void)e; }
+        if (icp->src_used[l]) { e = hipEventDestroy(icp->src_used[l]); (void)e; }
     }
+    if (icp->src_ready) { e = hipEventDestroy(icp->src_ready); (void)e; }
     if (icp->main_mark) { e = hipEventDestroy(icp->main_mark); (void)e; }
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
     if (icp->inits_ev) { e = hipEventDestroy(icp->inits_ev); (void)e; }
@@ -3901,12 +4007,16 @@ extern "C" int sf_icp_set_source_batch(sf_icp *icp, const float *xyz, int64_t n_
     SF_HIP(hipSetDevice(icp->ctx->device));
     std::vector<double> keep = icp->inits;
     const int64_t total = n_per_scan * batch;
+    // host memory has no producer on the device to wait for: with an alignment in flight the upload takes the other source set
+    // and the next lane's stream (SrcScope) -- the next batch is uploaded and converted beside the alignment, not behind it
+    SrcScope src(icp, true);
+    SF_TRY(src.rc);
     // persistent staging buffer, no allocation and no host synchronisation per scan: a copy from pageable host
     // memory is staged by the runtime before hipMemcpyAsync returns (the caller may reuse xyz at once); pinned
     // host memory is read asynchronously, stream-ordered -- then the caller owns the usual lifetime rule
     SF_TRY(icp->stage.reserve(sizeof(float) * 3 * (size_t)std::max<int64_t>(total, 1)));
     if (total > 0) SF_HIP(hipMemcpyAsync(icp->stage.p, xyz, sizeof(float) * 3 * (size_t)total, hipMemcpyHostToDevice, icp->ctx->stream));
-    int rc = icp_set_source_device_aos(icp, icp->stage.as<float>(), n_per_scan, batch);
+    int rc = icp_set_source_device_aos(icp, icp->stage.as<float>(), n_per_scan, batch, src.ahead);
     if (batch == 1 && keep.size() >= 16) icp->inits.assign(keep.begin(), keep.begin() + 16); // setters are order independent
     return rc;
 }
@@ -3917,6 +4027,8 @@ extern "C" int sf_icp_set_source_batch_device(sf_icp *icp, const void *d_xyz, in
     SF_CHECK(n_per_scan * batch < (int64_t)0x7fffffff, SF_ERR_OVERFLOW, "too many source points");
     SF_HIP(hipSetDevice(icp->ctx->device));
     std::vector<double> keep = icp->inits;
+    SrcScope src(icp, false); // whatever produced d_xyz is ordered on the context's stream: the conversion stays there, behind it
+    SF_TRY(src.rc);
     int rc = icp_set_source_device_aos(icp, reinterpret_cast<const float *>(d_xyz), n_per_scan, batch);
     if (batch == 1 && keep.size() >= 16) icp->inits.assign(keep.begin(), keep.begin() + 16);
     return rc;
@@ -3935,6 +4047,8 @@ extern "C" int sf_icp_set_source_scan(sf_icp *icp, sf_cloud *raw, int stride, co
     if (n_raw < stride) stride = 1; // point_cloud_processing.hpp:58-61: a cloud shorter than the step is left untouched
     const int64_t n_cand = sf::div_up(n_raw, stride);
     SF_CHECK(n_cand < ((int64_t)1 << 31) - 4096, SF_ERR_OVERFLOW, "too many points");
+    SrcScope src(icp, false); // (the raw cloud is a product of the context's stream)
+    SF_TRY(src.rc);
     SF_TRY(icp_alloc(icp, n_cand, 1)); // capacity: every candidate survives
     SF_TRY(icp->n_dev.reserve(sizeof(int)));
     hipStream_t s = icp->ctx->stream;
@@ -4178,13 +4292,6 @@ extern "C" int sf_icp_use_graph(sf_icp *icp, int on)
 }
 
 namespace {
-void raw_swap(sf::DevBuf &a, sf::DevBuf &b) // the allocations change places, epochs included (a captured graph keeps pointing at ITS lane's buffers)
-{
-    std::swap(a.p, b.p);
-    std::swap(a.cap, b.cap);
-    std::swap(a.epoch, b.epoch);
-}
-
 void lane_flip(sf_icp *icp)
 {
     sf_icp::Lane &o = icp->other;
@@ -4196,6 +4303,7 @@ void lane_flip(sf_icp *icp)
     std::swap(icp->graph_key, o.graph_key);
     std::swap(icp->inits_uploaded, o.inits_uploaded);
     std::swap(icp->d_inits_epoch, o.d_inits_epoch);
+    std::swap(icp->meta, icp->other_meta);
     icp->lane ^= 1;
 }
 
@@ -4221,16 +4329,21 @@ struct LaneScope {
     LaneScope(sf_icp *i, bool allowed) : icp(i)
     {
         main = icp->ctx->stream;
-        if (!allowed) return;
-        for (int l = 0; l < 2; ++l) {
-            if (!icp->lane_stream[l] && hipStreamCreateWithFlags(&icp->lane_stream[l], hipStreamNonBlocking) != hipSuccess) { rc = SF_ERR_HIP; return; }
-            if (!icp->lane_done[l] && hipEventCreateWithFlags(&icp->lane_done[l], hipEventDisableTiming) != hipSuccess) { rc = SF_ERR_HIP; return; }
+        rc = ensure_lanes(icp); // (every alignment marks the end of its reading of the source set: the events must exist)
+        if (rc != SF_OK) return;
+        if (!allowed) {
+            // the context's stream, the buffers at hand -- behind a source that was written on a lane's stream, if one was
+            if (icp->src_ahead) {
+                if (hipStreamWaitEvent(main, icp->src_ready, 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
+                icp->src_ahead = false;
+            }
+            return;
         }
-        if (!icp->main_mark && hipEventCreateWithFlags(&icp->main_mark, hipEventDisableTiming) != hipSuccess) { rc = SF_ERR_HIP; return; }
         // the mark: where the context's stream stood when the inputs last changed (taken before anything of this alignment is enqueued)
         const sf_map *m = icp->map;
+        // (the initial poses are not part of it: they travel in the kernel arguments or through the lane's own copy, on the lane's stream)
         const bool same = icp->mark_valid && icp->mark_src_version == icp->src_version && icp->mark_map == (const void *)m && icp->mark_map_generation == m->generation &&
-                          std::memcmp(&icp->mark_window, &m->window, sizeof(SfWindow)) == 0 && icp->mark_inits == icp->inits;
+                          std::memcmp(&icp->mark_window, &m->window, sizeof(SfWindow)) == 0;
         if (!same) {
             if (hipEventRecord(icp->main_mark, main) != hipSuccess) { rc = SF_ERR_HIP; return; }
             icp->mark_valid = true;
@@ -4238,16 +4351,19 @@ struct LaneScope {
             icp->mark_map = (const void *)m;
             icp->mark_map_generation = m->generation;
             icp->mark_window = m->window;
-            icp->mark_inits = icp->inits;
         }
-        if (!icp->unfetched) return; // nothing of this object in flight: the context's stream, the buffers at hand
-        lane_flip(icp); // take turns
+        if (!icp->unfetched && !icp->src_ahead) return; // nothing of this object in flight: the context's stream, the buffers at hand
+        lane_flip(icp); // take turns (a source written ahead went to this lane's stream)
         rc = lane_reserve(icp);
         if (rc != SF_OK) return;
         hipStream_t ls = icp->lane_stream[icp->lane];
         // after the inputs, and after this lane's previous alignment (which may have run on the context's stream)
         if (hipStreamWaitEvent(ls, icp->main_mark, 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
         if (icp->lane_used[icp->lane] && hipStreamWaitEvent(ls, icp->lane_done[icp->lane], 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
+        if (icp->src_ahead) {
+            if (hipStreamWaitEvent(ls, icp->src_ready, 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
+            icp->src_ahead = false;
+        }
         icp->ctx->stream = ls;
         piped = true;
     }
@@ -4255,7 +4371,8 @@ struct LaneScope {
     {
         hipStream_t ran = icp->ctx->stream;
         icp->ctx->stream = main;
-        if (!icp->lane_done[icp->lane]) return; // (not allowed: nothing to mark)
+        if (!icp->lane_done[icp->lane]) return; // (the lanes have never been set up: nothing to mark)
+        if (icp->src_used[icp->src_set] && hipEventRecord(icp->src_used[icp->src_set], ran) == hipSuccess) icp->src_used_rec[icp->src_set] = true; // the last reader of this source set
         if (hipEventRecord(icp->lane_done[icp->lane], ran) != hipSuccess) return;
         icp->lane_used[icp->lane] = true;
         // whatever the caller enqueues next on the context's stream is ordered behind this alignment
@@ -4273,9 +4390,16 @@ extern "C" int sf_icp_align_batch_async(sf_icp *icp, int mode)
     icp->last_fused = fused_eligible(icp, mode);
     SF_TRY(order_lut_prepare(icp));
     // the launch list takes a lane (see sf_icp::Lane); the single launch, profiled runs and a count left on the device stay on the context's stream
+    const bool beside = icp->unfetched; // an alignment of this object is still unfetched: this one may run beside it
     LaneScope lanes(icp, icp->pipeline != 0 && !icp->last_fused && !icp->profiling && !icp->n_on_device);
     SF_TRY(lanes.rc);
+    if (!lanes.piped) SF_TRY(lane_reserve(icp)); // (a source written ahead of an alignment in flight left the output buffers alone: icp_alloc)
     icp->unfetched = true;
+    icp->prev_ok = lanes.piped && beside && icp->other_meta.valid; // (not piped: this alignment runs in the buffers of the one before it)
+    icp->meta.valid = true;
+    icp->meta.batch = icp->batch;
+    icp->meta.mode = mode;
+    icp->meta.inits = icp->inits;
     hipStream_t s = icp->ctx->stream;
     SF_TRY(launch_state_init(icp));
     if (icp->last_fused) { // everything resident at once: the whole alignment is one launch (window and count by value)
@@ -4334,13 +4458,40 @@ extern "C" int sf_icp_fetch_results(sf_icp *icp, sf_icp_result *out)
 {
     SF_CHECK(icp && out, SF_ERR_INVALID, "bad arguments");
     SF_CHECK(icp->batch > 0, SF_ERR_STATE, "nothing to fetch");
-    SF_TRY(states_to_host(icp));
+    // the latest alignment as it was enqueued: a source or priors set since (for the NEXT alignment) do not describe it
+    const bool described = icp->meta.valid && icp->meta.batch > 0 && !icp->shard;
+    const int nb = described ? icp->meta.batch : icp->batch;
+    SF_TRY(states_to_host(icp, nb));
     icp->unfetched = false;
     fused_release(icp); // the grid has drained
     if (icp->profiling) prof_collect(icp);
-    SF_TRY(check_barrier_flags(icp));
-    for (int b = 0; b < icp->batch; ++b) fill_result(icp, icp->last_mode, icp->h_state[(size_t)b], &icp->inits[(size_t)b * 16], out + b);
-    freeze_learn_schedule(icp);
+    if (nb == icp->batch) SF_TRY(check_barrier_flags(icp));
+    for (int b = 0; b < nb; ++b)
+        fill_result(icp, described ? icp->meta.mode : icp->last_mode, icp->h_state[(size_t)b], described ? &icp->meta.inits[(size_t)b * 16] : &icp->inits[(size_t)b * 16], out + b);
+    if (nb == icp->batch) freeze_learn_schedule(icp);
+    return SF_OK;
+}
+
+// The alignment enqueued BEFORE the latest one, when the two ran side by side on the lanes (two sf_icp_align_batch_async
+// calls with no fetch between them): its states lie in the other lane's buffers until the next piped alignment takes
+// them.  Waits for that alignment only -- the latest one goes on running -- so "enqueue the next batch's alignment, fetch
+// the previous one's result" delivers every result without draining the device.
+extern "C" int sf_icp_fetch_previous(sf_icp *icp, sf_icp_result *out)
+{
+    SF_CHECK(icp && out, SF_ERR_INVALID, "bad arguments");
+    SF_CHECK(icp->prev_ok && icp->other_meta.valid && icp->other_meta.batch > 0, SF_ERR_STATE,
+             "no earlier alignment to fetch: the latest alignment did not run beside the one before it (fetched in between, pipeline off, single launch) or it was fetched already");
+    const int ol = icp->lane ^ 1;
+    const sf_icp::LaneMeta &M = icp->other_meta;
+    SF_CHECK(icp->lane_used[ol] && icp->lane_done[ol] && icp->lane_stream[ol] && icp->other.state.p, SF_ERR_STATE, "the other lane holds no alignment");
+    SF_HIP(hipSetDevice(icp->ctx->device));
+    SF_HIP(hipEventSynchronize(icp->lane_done[ol]));
+    icp->h_prev.resize((size_t)M.batch);
+    // on the other lane's own stream: neither the context's stream (it waits for the latest alignment) nor the null stream is touched
+    SF_HIP(hipMemcpyAsync(icp->h_prev.data(), icp->other.state.p, sizeof(IcpState) * (size_t)M.batch, hipMemcpyDeviceToHost, icp->lane_stream[ol]));
+    SF_HIP(hipStreamSynchronize(icp->lane_stream[ol]));
+    for (int b = 0; b < M.batch; ++b) fill_result(icp, M.mode, icp->h_prev[(size_t)b], &M.inits[(size_t)b * 16], out + b);
+    icp->prev_ok = false;
     return SF_OK;
 }
 

@@ -132,3 +132,97 @@ def test_random_call_sequences_equal_the_same_calls_on_one_lane(api, ctx, synth,
             bitwise(objs[0].fetch_results(), objs[1].fetch_results())
     if pending:
         bitwise(objs[0].fetch_results(), objs[1].fetch_results())
+
+
+def test_fetch_previous_delivers_every_result_of_a_stream(api, ctx, synth, world):
+    """The streaming loop of include/slamfusion.h (sf_icp_fetch_previous): enqueue the next alignment, fetch the one before it.
+    Every result is that of the same alignment run alone, bit for bit; new priors between the calls are seen by the next
+    alignment only."""
+    inits = [None] + [np.stack([synth.make_T((0.02 * k * s, -0.01 * s, 0.01), (0.1 * k, 0.05 * s, 0.2)) for k in range(4)]) for s in (1, 2, 3)]
+    alone = make(api, ctx, world, False, True)
+    want = []
+    for T in inits:
+        alone.set_initial_batch(T)
+        want.append(alone.align_batch("p2plane"))
+    icp = make(api, ctx, world, True, True)
+    got = []
+    for i, T in enumerate(inits):
+        icp.set_initial_batch(T)
+        icp.align_batch_async("p2plane")
+        if i > 0:
+            got.append(icp.fetch_previous())
+    got.append(icp.fetch_results())
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        bitwise(g, w)
+    # nothing left: the previous one was fetched, and after a fetch the next alignment takes the buffers at hand
+    with pytest.raises(api.SlamFusionError):
+        icp.fetch_previous()
+    icp.align_batch_async("p2plane")
+    with pytest.raises(api.SlamFusionError):
+        icp.fetch_previous()
+    bitwise(icp.fetch_results(), want[-1])
+
+
+def test_fetch_previous_across_modes_and_batch_sizes(api, ctx, synth, world):
+    """The earlier alignment is described by what it was enqueued with: another mode, another number of scans."""
+    icp = make(api, ctx, world, True, False)
+    alone = make(api, ctx, world, False, False)
+    icp.align_batch_async("o3d_p2p")                      # four scans, point-to-point
+    two = world["scans"][:2].copy()
+    icp.set_source_batch(two)
+    icp.set_initial_batch(None)
+    icp.align_batch_async("p2plane")                      # two scans, point-to-plane, beside it
+    first = icp.fetch_previous()
+    bitwise(first, alone.align_batch("o3d_p2p"))
+    alone.set_source_batch(two)
+    alone.set_initial_batch(None)
+    bitwise(icp.fetch_results(), alone.align_batch("p2plane"))
+    # pipeline off: alignments share one set of buffers, there is never a previous one to fetch
+    off = make(api, ctx, world, False, False)
+    off.align_batch_async("p2plane")
+    off.align_batch_async("p2plane")
+    with pytest.raises(api.SlamFusionError):
+        off.fetch_previous()
+    off.fetch_results()
+
+
+def test_a_stream_of_new_batches_equals_each_alone(api, ctx, synth, world):
+    """The whole streaming loop: a NEW source batch and new priors every step, set while the previous step's alignment is in
+    flight (the upload takes the other source set on the next lane's stream, sf_icp.hip SrcScope), the previous step's results
+    fetched while this step runs.  Every step's results are those of the same batch registered alone, bit for bit -- also when a
+    step sets its source twice, changes the number of scans, or fetches in between."""
+    rng = np.random.default_rng(11)
+    pool = [world["scans"], world["scans"][::-1].copy(), world["scans"][[1, 3, 0, 2]].copy(), world["scans"][:2].copy(), world["scans"][1:4].copy()]
+    plan = [0, 1, 2, 3, 1, 4, 0, 2, 2, 1]
+    steps = []
+    for i, k in enumerate(plan):
+        B = len(pool[k])
+        inits = np.stack([synth.make_T(rng.normal(0, 0.02, 3), rng.normal(0, 0.2, 3)) for _ in range(B)])
+        steps.append((k, inits))
+    alone = make(api, ctx, world, False, True)
+    want = []
+    for k, inits in steps:
+        alone.set_source_batch(pool[k])
+        alone.set_initial_batch(inits)
+        want.append(alone.align_batch("p2plane"))
+    for graph in (True, False):
+        icp = make(api, ctx, world, True, graph)
+        got, prev_batch = [], None
+        for i, (k, inits) in enumerate(steps):
+            if i == 4:
+                icp.set_source_batch(pool[0])             # a source that is replaced before any alignment reads it
+            icp.set_source_batch(pool[k])
+            icp.set_initial_batch(inits)
+            if i == 6:                                    # a fetch between the source and its alignment: the latest alignment, as it was enqueued
+                got.append(icp.fetch_results())
+                prev_batch = None
+            icp.align_batch_async("p2plane")
+            if prev_batch is not None:
+                got.append(icp.fetch_previous())
+            prev_batch = len(pool[k])
+        got.append(icp.fetch_results())
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert len(g) == len(w)
+            bitwise(g, w)
