@@ -3014,6 +3014,8 @@ struct sf_icp {
     hipEvent_t src_used[2] = {nullptr, nullptr}, src_ready = nullptr;
     bool src_used_rec[2] = {false, false};
     bool src_ahead = false;       // the members' source was written on a lane's stream (src_ready) and no alignment has been ordered behind it yet
+    hipEvent_t unmarked_ev = nullptr;
+    bool src_unmarked_use = false; // an alignment read a source set before the lanes' events existed (the per-scan path never creates them): the first source written ahead waits for the context's stream instead
     // what the lane's last alignment was (sf_icp_fetch_previous reads the OTHER lane's states with the other lane's description)
     struct LaneMeta {
         bool valid = false;
@@ -3309,6 +3311,7 @@ int ensure_lanes(sf_icp *icp)
     }
     if (!icp->main_mark) SF_HIP(hipEventCreateWithFlags(&icp->main_mark, hipEventDisableTiming));
     if (!icp->src_ready) SF_HIP(hipEventCreateWithFlags(&icp->src_ready, hipEventDisableTiming));
+    if (!icp->unmarked_ev) SF_HIP(hipEventCreateWithFlags(&icp->unmarked_ev, hipEventDisableTiming));
     return SF_OK;
 }
 
@@ -3339,6 +3342,10 @@ struct SrcScope {
         if (rc != SF_OK) return;
         if (!icp->src_ahead) src_flip(icp); // (a second source before any alignment: the same set, the same stream, again)
         hipStream_t ls = icp->lane_stream[icp->lane ^ 1];
+        if (icp->src_unmarked_use) { // readers that left no event: everything the context's stream holds
+            if (hipEventRecord(icp->unmarked_ev, main) != hipSuccess || hipStreamWaitEvent(ls, icp->unmarked_ev, 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
+            icp->src_unmarked_use = false;
+        }
         if (icp->src_used_rec[icp->src_set] && hipStreamWaitEvent(ls, icp->src_used[icp->src_set], 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
         icp->ctx->stream = ls;
         ahead = true;
@@ -3387,7 +3394,7 @@ int icp_alloc(sf_icp *icp, int64_t n, int batch, bool outputs = true)
         SF_TRY(icp->partials.reserve(sizeof(double) * (size_t)REC_STRIDE * (size_t)icp->nblocks * (size_t)batch));
         SF_TRY(icp->xchg_own.reserve(sizeof(double) * REC_STRIDE * (size_t)batch));
     }
-    if (icp->batch != batch || icp->inits.size() != (size_t)batch * 16) {
+    if (icp->inits.size() != (size_t)batch * 16) { // (by the priors' own size, not by the batch of whichever source set was at hand)
         icp->inits.assign((size_t)batch * 16, 0.0);
         for (int b = 0; b < batch; ++b)
             for (int d = 0; d < 4; ++d) icp->inits[(size_t)b * 16 + 5 * d] = 1.0;
@@ -3956,6 +3963,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
         if (icp->src_used[l]) { e = hipEventDestroy(icp->src_used[l]); (void)e; }
     }
     if (icp->src_ready) { e = hipEventDestroy(icp->src_ready); (void)e; }
+    if (icp->unmarked_ev) { e = hipEventDestroy(icp->unmarked_ev); (void)e; }
     if (icp->main_mark) { e = hipEventDestroy(icp->main_mark); (void)e; }
     for (hipEvent_t ev : icp->ev) { e = hipEventDestroy(ev); (void)e; }
     if (icp->inits_ev) { e = hipEventDestroy(icp->inits_ev); (void)e; }
@@ -4329,6 +4337,10 @@ struct LaneScope {
     LaneScope(sf_icp *i, bool allowed) : icp(i)
     {
         main = icp->ctx->stream;
+        if (!allowed && !icp->lane_done[0]) { // the per-scan path (single launch) of an object that has never piped: no streams, no events, nothing to record
+            icp->src_unmarked_use = true;
+            return;
+        }
         rc = ensure_lanes(icp); // (every alignment marks the end of its reading of the source set: the events must exist)
         if (rc != SF_OK) return;
         if (!allowed) {

@@ -226,3 +226,21 @@ def test_a_stream_of_new_batches_equals_each_alone(api, ctx, synth, world):
         for g, w in zip(got, want):
             assert len(g) == len(w)
             bitwise(g, w)
+
+
+def test_priors_set_before_the_next_source_are_kept(api, ctx, synth, world):
+    """The setters are order independent: priors set BEFORE a source of the same number of scans stay, also when that source goes
+    into the other source set because an alignment is in flight (whose batch size the set at hand may not share)."""
+    inits = np.stack([synth.make_T((0.03 * k, -0.02, 0.01), (0.1 * k, 0.0, 0.2)) for k in range(4)])
+    other = world["scans"][::-1].copy()
+    alone = make(api, ctx, world, False, True)
+    alone.set_source_batch(other)
+    alone.set_initial_batch(inits)
+    want = alone.align_batch("p2plane")
+    icp = make(api, ctx, world, True, True)
+    icp.align_batch_async("p2plane")
+    icp.set_initial_batch(inits)
+    icp.set_source_batch(other)                           # ahead of the alignment in flight: the first use of the second source set
+    icp.align_batch_async("p2plane")
+    icp.fetch_previous()
+    bitwise(icp.fetch_results(), want)
