@@ -333,7 +333,7 @@ int sf_icp_set_wide_scan_points(sf_icp *icp, int64_t points);
  * A source set FROM HOST MEMORY (sf_icp_set_source_batch / sf_icp_set_source) while an alignment is unfetched does not wait
  * for it either: the object keeps two source sets, the upload and its conversion take the one the alignment in flight does
  * not read, on the stream the next alignment will run on -- the streaming loop "set the next batch, enqueue its alignment,
- * sf_icp_fetch_previous" uploads batch k+1 beside the alignment of batch k (measured: +11 % over the same loop with the
+ * sf_icp_fetch_previous" uploads batch k+1 beside the alignment of batch k (measured: +41 % over the same loop with the
  * upload behind the alignment; profiles/LADDER.md).  Sources handed over as DEVICE pointers or clouds stay on the context's
  * stream, behind whatever produced them.
  * on: 1 (default) / 0 = every alignment on the context's stream.  No reference counterpart (one scan at a time,

@@ -3014,6 +3014,12 @@ struct sf_icp {
     hipEvent_t src_used[2] = {nullptr, nullptr}, src_ready = nullptr;
     bool src_used_rec[2] = {false, false};
     bool src_ahead = false;       // the members' source was written on a lane's stream (src_ready) and no alignment has been ordered behind it yet
+    // started[l]: recorded on lane l's stream when its latest alignment begins (behind everything it waits for).  A source written
+    // ahead starts its upload behind the START of the alignment on the other lane: two uploads issued back to back -- the host
+    // fetched two results that became ready together -- would otherwise share the link, end together and let both alignments
+    // start together, a lockstep in which nothing overlaps (measured: upload + upload, then alignment + alignment, for good).
+    hipEvent_t started[2] = {nullptr, nullptr};
+    bool started_rec[2] = {false, false};
     hipEvent_t unmarked_ev = nullptr;
     bool src_unmarked_use = false; // an alignment read a source set before the lanes' events existed (the per-scan path never creates them): the first source written ahead waits for the context's stream instead
     // what the lane's last alignment was (sf_icp_fetch_previous reads the OTHER lane's states with the other lane's description)
@@ -3308,6 +3314,7 @@ int ensure_lanes(sf_icp *icp)
         if (!icp->lane_stream[l]) SF_HIP(hipStreamCreateWithFlags(&icp->lane_stream[l], hipStreamNonBlocking));
         if (!icp->lane_done[l]) SF_HIP(hipEventCreateWithFlags(&icp->lane_done[l], hipEventDisableTiming));
         if (!icp->src_used[l]) SF_HIP(hipEventCreateWithFlags(&icp->src_used[l], hipEventDisableTiming));
+        if (!icp->started[l]) SF_HIP(hipEventCreateWithFlags(&icp->started[l], hipEventDisableTiming));
     }
     if (!icp->main_mark) SF_HIP(hipEventCreateWithFlags(&icp->main_mark, hipEventDisableTiming));
     if (!icp->src_ready) SF_HIP(hipEventCreateWithFlags(&icp->src_ready, hipEventDisableTiming));
@@ -3347,6 +3354,8 @@ struct SrcScope {
             icp->src_unmarked_use = false;
         }
         if (icp->src_used_rec[icp->src_set] && hipStreamWaitEvent(ls, icp->src_used[icp->src_set], 0) != hipSuccess) { rc = SF_ERR_HIP; return; }
+        static const bool stagger_on = []() { const char *e = std::getenv("SF_UPLOAD_STAGGER"); return !e || std::atoi(e) != 0; }(); // (A/B switch)
+        if (stagger_on && icp->started_rec[icp->lane] && hipStreamWaitEvent(ls, icp->started[icp->lane], 0) != hipSuccess) { rc = SF_ERR_HIP; return; } // see sf_icp::started
         icp->ctx->stream = ls;
         ahead = true;
     }
@@ -3961,6 +3970,7 @@ extern "C" void sf_icp_destroy(sf_icp *icp)
         if (icp->lane_stream[l]) { e = hipStreamSynchronize(icp->lane_stream[l]); (void)e; e = hipStreamDestroy(icp->lane_stream[l]); (void)e; }
         if (icp->lane_done[l]) { e = hipEventDestroy(icp->lane_done[l]); (void)e; }
         if (icp->src_used[l]) { e = hipEventDestroy(icp->src_used[l]); (void)e; }
+        if (icp->started[l]) { e = hipEventDestroy(icp->started[l]); (void)e; }
     }
     if (icp->src_ready) { e = hipEventDestroy(icp->src_ready); (void)e; }
     if (icp->unmarked_ev) { e = hipEventDestroy(icp->unmarked_ev); (void)e; }
@@ -4364,7 +4374,10 @@ struct LaneScope {
             icp->mark_map_generation = m->generation;
             icp->mark_window = m->window;
         }
-        if (!icp->unfetched && !icp->src_ahead) return; // nothing of this object in flight: the context's stream, the buffers at hand
+        if (!icp->unfetched && !icp->src_ahead) { // nothing of this object in flight: the context's stream, the buffers at hand
+            if (hipEventRecord(icp->started[icp->lane], main) == hipSuccess) icp->started_rec[icp->lane] = true;
+            return;
+        }
         lane_flip(icp); // take turns (a source written ahead went to this lane's stream)
         rc = lane_reserve(icp);
         if (rc != SF_OK) return;
@@ -4378,6 +4391,7 @@ struct LaneScope {
         }
         icp->ctx->stream = ls;
         piped = true;
+        if (hipEventRecord(icp->started[icp->lane], ls) == hipSuccess) icp->started_rec[icp->lane] = true;
     }
     ~LaneScope()
     {

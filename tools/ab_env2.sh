@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of environment switches of the library, several at once:  tools/ab_env2.sh "SF_STAGGER=0 SF_TAIL_PRIO=0" "SF_STAGGER=1 SF_TAIL_PRIO=1" ...
+# A/B of environment switches of the library, several at once:  tools/ab_env2.sh "SF_UPLOAD_STAGGER=0" "SF_UPLOAD_STAGGER=1" ...
 # per setting: the bench line's value (same source every step, every result fetched) and the streaming probe (a new batch from pinned host memory every step)
 cd "$GRAFT_REPO_ROOT"
 for rep in 1 2; do
