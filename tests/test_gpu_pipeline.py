@@ -244,3 +244,66 @@ def test_priors_set_before_the_next_source_are_kept(api, ctx, synth, world):
     icp.align_batch_async("p2plane")
     icp.fetch_previous()
     bitwise(icp.fetch_results(), want)
+
+
+def test_random_streams_deliver_every_result(api, ctx, synth, small_world):
+    """Seeded fuzz of the streaming loop: random sources (three batches of different sizes, set once or twice, before or after the
+    priors), priors, modes and iteration counts; one object streams -- enqueue, then sf_icp_fetch_previous, now and then a plain
+    fetch in between -- the other registers every step alone.  EVERY step's results must agree bit for bit.  Launch list only
+    (sf_icp_set_fused(0)); SF_FUZZ_TRIALS / SF_FUZZ_SEED override the defaults."""
+    import os
+    m = small_world["map"]
+    mp = api.Map(ctx, api.Cloud(ctx, m), 0.25)
+    mp.estimate_normals(0.25)
+    rng = np.random.default_rng(int(os.environ.get("SF_FUZZ_SEED", "9")))
+    pool = [np.stack([synth.make_scan(m, n, scan_id=400 + 5 * k + b)[0][:n] for b in range(nb)]) for k, (n, nb) in enumerate(((6000, 3), (4000, 2), (7000, 4)))]
+    objs = []
+    for pipe in (True, False):
+        icp = api.Icp(ctx, 0.5, 8, 0.05, 1e-5)
+        icp.set_target(mp)
+        icp.set_fused(False)
+        icp.use_graph(True)
+        icp.set_pipeline(pipe)
+        icp.set_source_batch(pool[0])
+        icp.set_initial_batch(None)
+        objs.append(icp)
+    stream, alone = objs
+    cur = 0
+    want, got = [], []
+    in_flight = 0        # alignments of `stream` enqueued and not fetched (0, 1 or 2)
+    for t in range(int(os.environ.get("SF_FUZZ_TRIALS", "80"))):
+        op = rng.choice(["align", "align", "align", "source", "inits", "iters", "fetch"])
+        if op == "source":
+            for _ in range(int(rng.integers(1, 3))):      # now and then a source that is replaced before it is read
+                cur = int(rng.integers(0, 3))
+                for icp in objs:
+                    icp.set_source_batch(pool[cur])
+                    icp.set_initial_batch(None)
+        elif op == "inits":
+            inits = np.stack([synth.make_T(rng.normal(0, 0.02, 3), rng.normal(0, 0.2, 3)) for _ in range(len(pool[cur]))])
+            for icp in objs:
+                icp.set_initial_batch(inits)
+        elif op == "iters":
+            it = int(rng.integers(1, 12))
+            for icp in objs:
+                icp.set_num_iterations(it)
+        elif op == "fetch":
+            if in_flight == 1:
+                got.append(stream.fetch_results())
+                in_flight = 0
+        else:
+            mode = str(rng.choice(["p2plane", "o3d_p2p", "ref_cpp"]))
+            want.append(alone.align_batch(mode))
+            if in_flight == 2:                            # (two in flight at most: the older one first)
+                raise AssertionError("test bookkeeping")
+            stream.align_batch_async(mode)
+            in_flight += 1
+            if in_flight == 2:
+                got.append(stream.fetch_previous())
+                in_flight = 1
+    if in_flight == 1:
+        got.append(stream.fetch_results())
+    assert len(got) == len(want) and len(want) > 10
+    for g, w in zip(got, want):
+        assert len(g) == len(w)
+        bitwise(g, w)
